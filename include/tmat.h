@@ -1,0 +1,144 @@
+/*
+ * tmat.h -- C-ABI of libtmat_hip.so: the MI355X (gfx950) implementation of the 2-D
+ * microvessel-branching hot path of fogg-lab/tissue-model-analysis-tools
+ * (scripts/compute_branches.py:307-361,391-426 and the fl_tissue_model_tools functions it drives).
+ *
+ * The reference is pure Python; a maintainer binds this library with ctypes (INTEGRATION.md shows
+ * the stub).  All buffers are caller-owned, contiguous, row-major.  Every function returns 0 on
+ * success or a negative code; tmat_last_error() returns a message for the calling thread.
+ * No torch / Python types cross this boundary.  Functions taking a `tmat_handle` run on that
+ * handle's HIP device and stream; a handle is not thread-safe, separate handles are independent.
+ *
+ * Pointer suffix convention:  *_dev arguments are HIP device pointers on the handle's device,
+ * everything else is host memory.
+ */
+#ifndef TMAT_H
+#define TMAT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tmat_ctx *tmat_handle;
+
+#define TMAT_OK 0
+#define TMAT_E_ARG (-1)     /* bad argument / unsupported shape            */
+#define TMAT_E_HIP (-2)     /* HIP runtime error (message has the detail)  */
+#define TMAT_E_WEIGHTS (-3) /* malformed weight blob                       */
+#define TMAT_E_CAP (-4)     /* caller-provided output capacity too small   */
+
+const char *tmat_last_error(void);
+/* 0x00MMmmpp */
+int tmat_version(void);
+
+/*
+ * Model life-cycle.  Replaces models.get_unet_patch_segmentor_from_cfg /
+ * UNetXceptionPatchSegmentor.__init__ (reference models.py:600-622, 656-684): builds the
+ * UNet-Xception of models.py:85-171 and loads its weights once per run (compute_branches.py:576).
+ * `weights_blob` is the "TMATW001" container (tmat_amd/synth.py:pack_weights; Keras tensor
+ * layouts) -- the offline stand-in for checkpoint_1.h5.
+ * `max_patches` bounds the UNet batch held in HBM at once (0 = default 400 = two 1024^2 images).
+ */
+int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max_patches, tmat_handle *out);
+void tmat_destroy(tmat_handle h);
+/* blocks until all work queued on the handle's stream is done */
+int tmat_sync(tmat_handle h);
+
+/*
+ * keras_model.predict on a patch batch (reference models.py:644 as called from
+ * smooth_tiled_predictions.py:179,182): x (n, P, P) f32 -> y (n, P, P) f32 sigmoid output
+ * (the trailing channel axis of size 1 is implicit).  P = patch size of the blob (320).
+ */
+int tmat_unet_predict(tmat_handle h, const float *x, int n, float *y);
+
+/*
+ * UNetXceptionPatchSegmentor.predict(x, auto_resample=False) (reference models.py:624-653) =
+ * predict_img_with_smooth_windowing(x, window_size=P, subdivisions=2, pred_func=model.predict)
+ * (smooth_tiled_predictions.py:220-267): pad, 8 D4 copies, 50 %-overlap tiles, UNet, squared-spline
+ * window, f64 overlap-add, D4 undo + mean, unpad.  x: (n, h, w) f32; pred: (n, h, w) f64.
+ */
+int tmat_predict_smooth(tmat_handle h, const float *x, int n, int hh, int ww, double *pred);
+
+/*
+ * compute_branches.py:309-328 for a batch: cv2.resize(img, round(shape * ds_ratio), INTER_LANCZOS4)
+ * -> rescale_intensity(out_range=(0,1)).astype(f32) -> model.predict(auto_resample=False).
+ * imgs: (n, H, W) u16; pred: (n, round(H*ds_ratio), round(W*ds_ratio)) f64.
+ */
+int tmat_segment_batch(tmat_handle h, const uint16_t *imgs, int n, int H, int W, float ds_ratio, double *pred);
+
+/*
+ * compute_branches.py:334-361 for a batch: pred > 0.5 -> filter_branch_seg_mask
+ * (transforms.py:306-361) -> medial_axis + EDT centre-line weighting -> skimage resize to
+ * (round(h * ds_width / w), ds_width), order 1, anti-aliased -> f32.
+ * pred: (n, h, w) f64; field: (n, fh, ds_width) f32 with fh = round(h * ds_width / w).
+ */
+int tmat_postprocess_batch(tmat_handle h, const double *pred, int n, int hh, int ww, int ds_width, float *field);
+
+/*
+ * fl_tissue_model_tools.dmtgraph.compute_dmt_graph(img, delta1, delta2) (reference
+ * dmtgraph.py:38-99; the contract the un-vendored pydmtgraph C++ extension exposed).
+ * img: (rows, cols) f32.  verts: (cap_v, 2) int32 [row, col]; edges: (cap_e, 2) int32.
+ * `h` may be NULL (host-only execution of the sequential sweeps).
+ */
+int tmat_dmt_graph(tmat_handle h, const float *img, int rows, int cols, float delta1, float delta2,
+                   int32_t *verts, int cap_v, int32_t *edges, int cap_e, int *n_verts, int *n_edges);
+
+/*
+ * topology.MorseGraph(img, thresholds, min_branch_length, max_branch_length,
+ * remove_isolated_branches, smoothing_window, pruning_mask) downstream of compute_dmt_graph
+ * (reference topology.py:148-179, 181-356): smoothing, trimming, spanning forest, branch labels,
+ * barcode, min-length filter.  verts/edges are compute_dmt_graph's outputs.
+ * max_branch_length <= 0 means None.  pruning_mask (rows, cols) u8 or NULL.
+ * Outputs: *count = len(barcode); *total_px = get_total_branch_length();
+ * *avg_px = get_average_branch_length(); bars (cap, 2) f64 [birth, death] (may be NULL).
+ */
+int tmat_morse_stats(const int32_t *verts, int n_verts, const int32_t *edges, int n_edges, int rows, int cols,
+                     int smoothing_window, int min_branch_length, int max_branch_length,
+                     int remove_isolated_branches, const uint8_t *pruning_mask, int64_t *count,
+                     double *total_px, double *avg_px, double *bars, int cap);
+
+/* One result row per image, the payload gathered across ranks. */
+typedef struct tmat_row {
+    int64_t index;   /* image index in the run                      */
+    int64_t count;   /* Total # of branches                         */
+    double total_px; /* total branch length in 384-wide pixels      */
+    double avg_px;   /* average branch length in 384-wide pixels    */
+} tmat_row;
+
+/*
+ * The whole per-image compute of analyze_img's 2-D branch (compute_branches.py:307-361, 391-426,
+ * 455-457) for a batch with inputs ALREADY RESIDENT IN HBM: imgs_dev (n, H, W) u16 device pointer.
+ * rows: n host records (index field = first_index + i).  graph_thresh_1/2, smoothing_window_px,
+ * min_branch_length_px, max_branch_length_px (<=0: none), remove_isolated: as computed at
+ * compute_branches.py:401-426.
+ */
+int tmat_analyze_batch_dev(tmat_handle h, const uint16_t *imgs_dev, int n, int H, int W, float ds_ratio,
+                           int ds_width, float graph_thresh_1, float graph_thresh_2, int smoothing_window_px,
+                           int min_branch_length_px, int max_branch_length_px, int remove_isolated,
+                           int64_t first_index, tmat_row *rows);
+
+/* host-pointer convenience wrapper of the above (uploads imgs first) */
+int tmat_analyze_batch(tmat_handle h, const uint16_t *imgs, int n, int H, int W, float ds_ratio, int ds_width,
+                       float graph_thresh_1, float graph_thresh_2, int smoothing_window_px,
+                       int min_branch_length_px, int max_branch_length_px, int remove_isolated,
+                       int64_t first_index, tmat_row *rows);
+
+/* device memory helpers so a ctypes host can stage inputs in HBM without torch */
+int tmat_dev_alloc(tmat_handle h, size_t bytes, void **dev_ptr);
+int tmat_dev_free(tmat_handle h, void *dev_ptr);
+int tmat_dev_upload(tmat_handle h, void *dev_dst, const void *host_src, size_t bytes);
+
+/*
+ * Timing hook for bench.py's roofline line: accumulated HIP-event time (ms) and launch count of
+ * the dominant kernel family (3x3 implicit-GEMM MFMA convolutions) since the last reset, measured
+ * on the handle's own stream.  flops = algorithmic FLOPs of those launches.
+ */
+int tmat_prof_enable(tmat_handle h, int on);
+int tmat_prof_read(tmat_handle h, double *ms, int64_t *launches, double *flops, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

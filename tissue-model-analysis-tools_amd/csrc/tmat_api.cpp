@@ -1,0 +1,448 @@
+// C-ABI entry points of libtmat_hip.so (see include/tmat.h) -- context, weights, UNet driver,
+// smooth tiled prediction.  gfx950 only; there is deliberately no CPU fallback: every compute
+// entry point needs a HIP device and fails loudly without one.
+#include "../../include/tmat.h"
+#include "tmat_ctx.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace tmat {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+bool hip_ok(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return true;
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight container ("TMATW001", tmat_amd/synth.py:pack_weights)
+// ---------------------------------------------------------------------------------------------
+struct Tensor { std::vector<int> shape; const float *data; size_t count; };
+
+static bool parse_blob(const void *blob, size_t nbytes, std::map<std::string, Tensor> &out, int &patch)
+{
+    const uint8_t *p = (const uint8_t *)blob;
+    if (nbytes < 16 || memcmp(p, "TMATW001", 8)) { set_error("weights: bad magic"); return false; }
+    uint32_t n, ps;
+    memcpy(&n, p + 8, 4); memcpy(&ps, p + 12, 4);
+    patch = (int)ps;
+    size_t pos = 16;
+    for (uint32_t i = 0; i < n; i++, pos += 84) {
+        if (pos + 84 > nbytes) { set_error("weights: truncated table"); return false; }
+        char name[49]; memcpy(name, p + pos, 48); name[48] = 0;
+        uint32_t ndim, d[4]; uint64_t off, cnt;
+        memcpy(&ndim, p + pos + 48, 4); memcpy(d, p + pos + 52, 16);
+        memcpy(&off, p + pos + 68, 8); memcpy(&cnt, p + pos + 76, 8);
+        if (ndim > 4 || off % 4 || off + cnt * 4 > nbytes) { set_error("weights: bad entry"); return false; }
+        Tensor t; t.data = (const float *)(p + off); t.count = cnt;
+        size_t prod = 1;
+        for (uint32_t k = 0; k < ndim; k++) { t.shape.push_back((int)d[k]); prod *= d[k]; }
+        if (prod != cnt) { set_error("weights: shape/count mismatch"); return false; }
+        out[name] = t;
+    }
+    return true;
+}
+
+static bool upload(Ctx *c, const std::vector<float> &v, float **dev)
+{
+    if (!hip_ok(hipMalloc((void **)dev, v.size() * sizeof(float)), "hipMalloc(weights)")) return false;
+    c->owned.push_back(*dev);
+    return hip_ok(hipMemcpy(*dev, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(weights)");
+}
+
+// scale = f32(gamma / sqrt(var + eps)); shift = f32(beta + (bias - mean) * scale_f64)   (BN folding)
+static void fold_bn(const Tensor &bn, const Tensor &bias, std::vector<float> &scale, std::vector<float> &shift)
+{
+    int C = bn.shape[1];
+    scale.resize(C); shift.resize(C);
+    for (int i = 0; i < C; i++) {
+        double g = bn.data[i], b = bn.data[C + i], m = bn.data[2 * C + i], v = bn.data[3 * C + i];
+        double sd = g / std::sqrt(v + 1e-3);
+        scale[i] = (float)sd;
+        shift[i] = (float)(b + ((double)bias.data[i] - m) * sd);
+    }
+}
+
+// Keras Conv2DTranspose kernel (kh, kw, out, in), stride 1, SAME -> conv taps
+// Wc[a][b][in][out] = K[2-a][2-b][out][in]
+static std::vector<float> convt_as_conv(const Tensor &k)
+{
+    int O = k.shape[2], I = k.shape[3];
+    std::vector<float> w((size_t)9 * I * O);
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++)
+            for (int i = 0; i < I; i++)
+                for (int o = 0; o < O; o++)
+                    w[(((size_t)a * 3 + b) * I + i) * O + o] = k.data[(((size_t)(2 - a) * 3 + (2 - b)) * O + o) * I + i];
+    return w;
+}
+
+static bool need(const std::map<std::string, Tensor> &m, const std::string &k, Tensor &t)
+{
+    auto it = m.find(k);
+    if (it == m.end()) { set_error("weights: missing tensor " + k); return false; }
+    t = it->second;
+    return true;
+}
+
+static bool build_model(Ctx *c, const std::map<std::string, Tensor> &m)
+{
+    Tensor w, b, bn;
+    std::vector<float> sc, sh;
+    if (!need(m, "stem.w", w) || !need(m, "stem.b", b) || !need(m, "stem.bn", bn)) return false;
+    if (w.shape.size() != 4 || w.shape[2] != 1) { set_error("weights: only channels=1 supported"); return false; }
+    c->f0 = w.shape[3];
+    fold_bn(bn, b, sc, sh);
+    if (!upload(c, std::vector<float>(w.data, w.data + w.count), &c->stem_w) || !upload(c, sc, &c->stem_scale) ||
+        !upload(c, sh, &c->stem_shift)) return false;
+    int cin = c->f0;
+    for (int i = 0;; i++) {
+        std::string p = "down" + std::to_string(i);
+        if (!m.count(p + ".sep1.dw")) break;
+        DownBlock d; d.cin = cin;
+        Tensor dw, pw, rb;
+        for (int s = 0; s < 2; s++) {
+            std::string sp = p + (s ? ".sep2" : ".sep1");
+            if (!need(m, sp + ".dw", dw) || !need(m, sp + ".pw", pw) || !need(m, sp + ".b", b) ||
+                !need(m, p + (s ? ".bn2" : ".bn1"), bn)) return false;
+            fold_bn(bn, b, sc, sh);
+            if (!upload(c, std::vector<float>(dw.data, dw.data + dw.count), &d.dw[s]) ||
+                !upload(c, std::vector<float>(pw.data, pw.data + pw.count), &d.pw[s]) || !upload(c, sc, &d.scale[s]) ||
+                !upload(c, sh, &d.shift[s])) return false;
+            d.cout = pw.shape[1];
+        }
+        if (!need(m, p + ".res.w", w) || !need(m, p + ".res.b", rb)) return false;
+        if (!upload(c, std::vector<float>(w.data, w.data + w.count), &d.res_w) ||
+            !upload(c, std::vector<float>(rb.data, rb.data + rb.count), &d.res_b)) return false;
+        c->down.push_back(d);
+        cin = d.cout;
+    }
+    for (int j = 0;; j++) {
+        std::string p = "up" + std::to_string(j);
+        if (!m.count(p + ".ct1.w")) break;
+        UpBlock u; u.cin = cin;
+        Tensor rb;
+        for (int s = 0; s < 2; s++) {
+            std::string sp = p + (s ? ".ct2" : ".ct1");
+            if (!need(m, sp + ".w", w) || !need(m, sp + ".b", b) || !need(m, p + (s ? ".bn2" : ".bn1"), bn)) return false;
+            if (w.shape.size() != 4 || w.shape[0] != 3 || w.shape[1] != 3) { set_error("weights: ConvT must be 3x3"); return false; }
+            fold_bn(bn, b, sc, sh);
+            if (!upload(c, convt_as_conv(w), &u.ct[s]) || !upload(c, sc, &u.scale[s]) || !upload(c, sh, &u.shift[s])) return false;
+            u.cout = w.shape[2];
+        }
+        if (!need(m, p + ".res.w", w) || !need(m, p + ".res.b", rb)) return false;
+        if (!upload(c, std::vector<float>(w.data, w.data + w.count), &u.res_w) ||
+            !upload(c, std::vector<float>(rb.data, rb.data + rb.count), &u.res_b)) return false;
+        c->up.push_back(u);
+        cin = u.cout;
+    }
+    if (!need(m, "final.w", w) || !need(m, "final.b", b)) return false;
+    if (!upload(c, std::vector<float>(w.data, w.data + w.count), &c->final_w)) return false;
+    c->final_b = b.data[0];
+    c->f_last = cin;
+    if (c->down.size() != c->up.size() - 1 || c->down.empty()) { set_error("weights: unexpected block structure"); return false; }
+    int P = c->patch;
+    if (P % (2 << c->down.size()) || P <= 0) { set_error("weights: patch size must be divisible by 2^(blocks+1)"); return false; }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// UNet forward on device patches X (n, P, P) -> Y (n, P, P); n <= max_patches.
+// Buffer plan (4 ping-pong activation buffers) is documented in DESIGN.md.
+// ---------------------------------------------------------------------------------------------
+static void prof_begin(Ctx *c, double flops)
+{
+    if (!c->prof_on) return;
+    hipEvent_t e0, e1;
+    if (c->ev_pool.size() >= 2) { e0 = c->ev_pool.back(); c->ev_pool.pop_back(); e1 = c->ev_pool.back(); c->ev_pool.pop_back(); }
+    else { hipEventCreate(&e0); hipEventCreate(&e1); }
+    hipEventRecord(e0, c->stream);
+    c->ev_open.push_back({e0, e1, flops});
+}
+static void prof_end(Ctx *c)
+{
+    if (!c->prof_on) return;
+    hipEventRecord(c->ev_open.back().e1, c->stream);
+}
+
+static bool conv(Ctx *c, ConvArgs a)
+{
+    bool dom = a.ksize == 3;
+    if (dom) {
+        double H = (double)(a.h << a.up), W = (double)(a.w << a.up);
+        prof_begin(c, 2.0 * a.N * H * W * 9.0 * a.Cin * a.Cout);
+    }
+    bool ok = launch_conv(a, c->stream);
+    if (dom) prof_end(c);
+    return ok;
+}
+
+int unet_forward_dev(Ctx *c, const float *X, int n, float *Y)
+{
+    if (n <= 0) return TMAT_OK;
+    if (n > c->max_patches) { set_error("unet_forward_dev: n > max_patches"); return TMAT_E_ARG; }
+    hipStream_t s = c->stream;
+    const int P = c->patch;
+    float *b0 = c->buf[0], *b1 = c->buf[1], *b2 = c->buf[2], *b3 = c->buf[3];
+    launch_stem(X, n, P, P, c->stem_w, c->f0, c->stem_scale, c->stem_shift, b0, s);
+    int H = P / 2;
+    for (auto &d : c->down) {
+        // prev = b0 (n, H, H, cin)
+        launch_dwconv(b0, n, H, H, d.cin, 1, d.dw[0], b1, s);
+        ConvArgs a{};
+        a.in = b1; a.N = n; a.h = H; a.w = H; a.Cin = d.cin; a.up = 0; a.relu_in = 0; a.ksize = 1; a.stride = 1;
+        a.W = d.pw[0]; a.Cout = d.cout; a.scale = d.scale[0]; a.shift = d.shift[0]; a.resid = nullptr; a.rs = 0;
+        a.relu_out = 1; a.out = b2;
+        if (!conv(c, a)) return TMAT_E_ARG;
+        launch_dwconv(b2, n, H, H, d.cout, 0, d.dw[1], b3, s);
+        a.in = b3; a.Cin = d.cout; a.W = d.pw[1]; a.scale = d.scale[1]; a.shift = d.shift[1]; a.relu_out = 0; a.out = b2;
+        if (!conv(c, a)) return TMAT_E_ARG;
+        ConvArgs r{};
+        r.in = b0; r.N = n; r.h = H; r.w = H; r.Cin = d.cin; r.ksize = 1; r.stride = 2; r.W = d.res_w; r.Cout = d.cout;
+        r.scale = nullptr; r.shift = d.res_b; r.out = b1;
+        if (!conv(c, r)) return TMAT_E_ARG;
+        launch_maxpool_add(b2, n, H, H, d.cout, b1, b0, s);
+        H /= 2;
+    }
+    // up path: S = stored tensor at resolution Hs; logical block input = Up^up(S)
+    float *S = b0;
+    int Hs = H, up = 0;
+    float *free3[3] = {b1, b2, b3};
+    for (auto &u : c->up) {
+        float *t1 = free3[0], *rr = free3[1], *so = free3[2];
+        ConvArgs a{};
+        a.in = S; a.N = n; a.h = Hs; a.w = Hs; a.Cin = u.cin; a.up = up; a.relu_in = 1; a.ksize = 3; a.stride = 1;
+        a.W = u.ct[0]; a.Cout = u.cout; a.scale = u.scale[0]; a.shift = u.shift[0]; a.relu_out = 1; a.out = t1;
+        if (!conv(c, a)) return TMAT_E_ARG;
+        ConvArgs r{};
+        r.in = S; r.N = n; r.h = Hs; r.w = Hs; r.Cin = u.cin; r.ksize = 1; r.stride = 1; r.W = u.res_w; r.Cout = u.cout;
+        r.scale = nullptr; r.shift = u.res_b; r.out = rr;
+        if (!conv(c, r)) return TMAT_E_ARG;
+        const int Hl = Hs << up;
+        ConvArgs b{};
+        b.in = t1; b.N = n; b.h = Hl; b.w = Hl; b.Cin = u.cout; b.up = 0; b.relu_in = 0; b.ksize = 3; b.stride = 1;
+        b.W = u.ct[1]; b.Cout = u.cout; b.scale = u.scale[1]; b.shift = u.shift[1]; b.resid = rr; b.rs = up; b.relu_out = 0;
+        b.out = so;
+        if (!conv(c, b)) return TMAT_E_ARG;
+        free3[2] = S; S = so;      // old S becomes free
+        Hs = Hl; up = 1;
+    }
+    launch_final(S, n, Hs, Hs, c->f_last, c->final_w, c->final_b, Y, s);
+    TMAT_HIP(hipGetLastError());
+    return TMAT_OK;
+}
+
+// predict_img_with_smooth_windowing on device: x_dev (n, hh, ww) f32 -> pred_dev (n, hh, ww) f64
+int predict_smooth_dev(Ctx *c, const float *x_dev, int n, int hh, int ww, double *pred_dev)
+{
+    const int P = c->patch;
+    TileGeom g = make_geom(hh, ww, P);
+    if (g.tiles_per_img > c->max_patches) { set_error("predict_smooth: image needs more patches than max_patches"); return TMAT_E_ARG; }
+    const int per_pass = c->max_patches / g.tiles_per_img;
+    size_t need_pv = (size_t)std::min(n, per_pass) * 2 * sizeof(float);
+    if (need_pv > c->scratch_bytes) { set_error("predict_smooth: scratch too small"); return TMAT_E_ARG; }
+    float *mn = (float *)c->scratch, *mx = mn + std::min(n, per_pass);
+    for (int i0 = 0; i0 < n; i0 += per_pass) {
+        int k = std::min(per_pass, n - i0);
+        const float *xi = x_dev + (size_t)i0 * hh * ww;
+        launch_minmax_f32(xi, k, (size_t)hh * ww, mn, mx, c->stream);
+        launch_extract_tiles(xi, mn, k, g, c->patch_in, c->stream);
+        int rc = unet_forward_dev(c, c->patch_in, k * g.tiles_per_img, c->patch_out);
+        if (rc) return rc;
+        launch_blend(c->patch_out, c->win1d, k, g, pred_dev + (size_t)i0 * hh * ww, c->stream);
+    }
+    TMAT_HIP(hipGetLastError());
+    return TMAT_OK;
+}
+
+}  // namespace tmat
+
+using namespace tmat;
+
+extern "C" {
+
+const char *tmat_last_error(void) { return g_err.c_str(); }
+int tmat_version(void) { return 0x000100; }
+
+int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max_patches, tmat_handle *out)
+{
+    if (!out || !weights_blob) { set_error("tmat_create: null argument"); return TMAT_E_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("tmat_create: no HIP device available (libtmat_hip has no CPU fallback)");
+        return TMAT_E_HIP;
+    }
+    if (device_id < 0 || device_id >= ndev) { set_error("tmat_create: bad device id"); return TMAT_E_ARG; }
+    TMAT_HIP(hipSetDevice(device_id));
+    std::map<std::string, Tensor> m;
+    int patch = 0;
+    if (!parse_blob(weights_blob, n_bytes, m, patch)) return TMAT_E_WEIGHTS;
+    Ctx *c = new Ctx();
+    c->device = device_id;
+    c->patch = patch;
+    c->max_patches = max_patches > 0 ? max_patches : 400;
+    if (!hip_ok(hipStreamCreate(&c->stream), "hipStreamCreate") || !build_model(c, m)) { tmat_destroy((tmat_handle)c); return TMAT_E_WEIGHTS; }
+    // activation workspace: per patch (P/2)^2 * f0 floats for buf0/buf1 and twice that for buf2/buf3
+    const size_t unit = (size_t)(patch / 2) * (patch / 2) * c->f0;
+    const size_t sizes[4] = {unit, unit, 2 * unit, 2 * unit};
+    for (int i = 0; i < 4; i++) {
+        if (!hip_ok(hipMalloc((void **)&c->buf[i], sizes[i] * c->max_patches * sizeof(float)), "hipMalloc(activations)")) {
+            tmat_destroy((tmat_handle)c); return TMAT_E_HIP;
+        }
+    }
+    const size_t pp = (size_t)patch * patch * c->max_patches * sizeof(float);
+    c->scratch_bytes = 64 << 20;
+    if (!hip_ok(hipMalloc((void **)&c->patch_in, pp), "hipMalloc(patch_in)") ||
+        !hip_ok(hipMalloc((void **)&c->patch_out, pp), "hipMalloc(patch_out)") ||
+        !hip_ok(hipMalloc((void **)&c->scratch, c->scratch_bytes), "hipMalloc(scratch)")) { tmat_destroy((tmat_handle)c); return TMAT_E_HIP; }
+    // squared-spline window (smooth_tiled_predictions.py:26-41), f64, on host then uploaded
+    {
+        const int ws = patch;
+        std::vector<double> tri(ws), wind(ws);
+        for (int i = 0; i < ws / 2; i++) { tri[i] = (2.0 * (i + 1) - 1.0) / ws; tri[ws - 1 - i] = tri[i]; }
+        const int isec = ws / 4;
+        double sum = 0;
+        for (int i = 0; i < ws; i++) {
+            double a2 = std::fabs(2 * tri[i]); double outer = (a2 * a2) / 2;
+            if (i >= isec && i < ws - isec) outer = 0;
+            double b2 = std::fabs(2 * (tri[i] - 1)); double inner = 1 - (b2 * b2) / 2;
+            if (i < isec || i >= ws - isec) inner = 0;
+            wind[i] = inner + outer;
+        }
+        // np.average = np.mean: pairwise summation in numpy; ws <= 8*128 blocks... restate numpy's
+        // pairwise add.reduce for n < 8*PW_BLOCKSIZE? (n=320 > 128 -> pairwise halves)
+        c->win_host = wind;
+        sum = numpy_pairwise_sum(wind.data(), ws);
+        double avg = sum / ws;
+        for (int i = 0; i < ws; i++) wind[i] = wind[i] / avg;
+        if (!hip_ok(hipMalloc((void **)&c->win1d, ws * sizeof(double)), "hipMalloc(win)") ||
+            !hip_ok(hipMemcpy(c->win1d, wind.data(), ws * sizeof(double), hipMemcpyHostToDevice), "hipMemcpy(win)")) {
+            tmat_destroy((tmat_handle)c); return TMAT_E_HIP;
+        }
+        c->win_host = wind;
+    }
+    *out = (tmat_handle)c;
+    return TMAT_OK;
+}
+
+void tmat_destroy(tmat_handle h)
+{
+    Ctx *c = (Ctx *)h;
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (void *p : c->owned) hipFree(p);
+    for (int i = 0; i < 4; i++) if (c->buf[i]) hipFree(c->buf[i]);
+    if (c->patch_in) hipFree(c->patch_in);
+    if (c->patch_out) hipFree(c->patch_out);
+    if (c->scratch) hipFree(c->scratch);
+    if (c->win1d) hipFree(c->win1d);
+    for (auto &e : c->ev_open) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
+    for (auto e : c->ev_pool) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int tmat_sync(tmat_handle h)
+{
+    Ctx *c = (Ctx *)h;
+    if (!c) { set_error("null handle"); return TMAT_E_ARG; }
+    TMAT_HIP(hipStreamSynchronize(c->stream));
+    return TMAT_OK;
+}
+
+int tmat_unet_predict(tmat_handle h, const float *x, int n, float *y)
+{
+    Ctx *c = (Ctx *)h;
+    if (!c || !x || !y || n < 0) { set_error("tmat_unet_predict: bad argument"); return TMAT_E_ARG; }
+    TMAT_HIP(hipSetDevice(c->device));
+    const size_t per = (size_t)c->patch * c->patch;
+    for (int i0 = 0; i0 < n; i0 += c->max_patches) {
+        int k = std::min(c->max_patches, n - i0);
+        TMAT_HIP(hipMemcpyAsync(c->patch_in, x + i0 * per, k * per * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        int rc = unet_forward_dev(c, c->patch_in, k, c->patch_out);
+        if (rc) return rc;
+        TMAT_HIP(hipMemcpyAsync(y + i0 * per, c->patch_out, k * per * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        TMAT_HIP(hipStreamSynchronize(c->stream));
+    }
+    return TMAT_OK;
+}
+
+int tmat_predict_smooth(tmat_handle h, const float *x, int n, int hh, int ww, double *pred)
+{
+    Ctx *c = (Ctx *)h;
+    if (!c || !x || !pred || n < 0 || hh <= 0 || ww <= 0) { set_error("tmat_predict_smooth: bad argument"); return TMAT_E_ARG; }
+    if (n == 0) return TMAT_OK;
+    TMAT_HIP(hipSetDevice(c->device));
+    const size_t per = (size_t)hh * ww;
+    float *xd = nullptr; double *pd = nullptr;
+    TMAT_HIP(hipMalloc((void **)&xd, n * per * sizeof(float)));
+    if (!hip_ok(hipMalloc((void **)&pd, n * per * sizeof(double)), "hipMalloc(pred)")) { hipFree(xd); return TMAT_E_HIP; }
+    int rc = TMAT_OK;
+    if (!hip_ok(hipMemcpyAsync(xd, x, n * per * sizeof(float), hipMemcpyHostToDevice, c->stream), "H2D")) rc = TMAT_E_HIP;
+    if (!rc) rc = predict_smooth_dev(c, xd, n, hh, ww, pd);
+    if (!rc && !hip_ok(hipMemcpyAsync(pred, pd, n * per * sizeof(double), hipMemcpyDeviceToHost, c->stream), "D2H")) rc = TMAT_E_HIP;
+    if (!hip_ok(hipStreamSynchronize(c->stream), "sync") && !rc) rc = TMAT_E_HIP;
+    hipFree(xd); hipFree(pd);
+    return rc;
+}
+
+int tmat_dev_alloc(tmat_handle h, size_t bytes, void **dev_ptr)
+{
+    Ctx *c = (Ctx *)h;
+    if (!c || !dev_ptr) { set_error("tmat_dev_alloc: bad argument"); return TMAT_E_ARG; }
+    TMAT_HIP(hipSetDevice(c->device));
+    TMAT_HIP(hipMalloc(dev_ptr, bytes));
+    return TMAT_OK;
+}
+int tmat_dev_free(tmat_handle h, void *dev_ptr)
+{
+    Ctx *c = (Ctx *)h;
+    if (!c) { set_error("null handle"); return TMAT_E_ARG; }
+    TMAT_HIP(hipSetDevice(c->device));
+    TMAT_HIP(hipFree(dev_ptr));
+    return TMAT_OK;
+}
+int tmat_dev_upload(tmat_handle h, void *dev_dst, const void *host_src, size_t bytes)
+{
+    Ctx *c = (Ctx *)h;
+    if (!c || !dev_dst || !host_src) { set_error("tmat_dev_upload: bad argument"); return TMAT_E_ARG; }
+    TMAT_HIP(hipSetDevice(c->device));
+    TMAT_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, c->stream));
+    TMAT_HIP(hipStreamSynchronize(c->stream));
+    return TMAT_OK;
+}
+
+int tmat_prof_enable(tmat_handle h, int on)
+{
+    Ctx *c = (Ctx *)h;
+    if (!c) { set_error("null handle"); return TMAT_E_ARG; }
+    c->prof_on = on != 0;
+    return TMAT_OK;
+}
+int tmat_prof_read(tmat_handle h, double *ms, int64_t *launches, double *flops, int reset)
+{
+    Ctx *c = (Ctx *)h;
+    if (!c) { set_error("null handle"); return TMAT_E_ARG; }
+    TMAT_HIP(hipSetDevice(c->device));
+    TMAT_HIP(hipStreamSynchronize(c->stream));
+    for (auto &e : c->ev_open) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, e.e0, e.e1) == hipSuccess) { c->prof_ms += t; c->prof_launches++; c->prof_flops += e.flops; }
+        c->ev_pool.push_back(e.e0); c->ev_pool.push_back(e.e1);
+    }
+    c->ev_open.clear();
+    if (ms) *ms = c->prof_ms;
+    if (launches) *launches = c->prof_launches;
+    if (flops) *flops = c->prof_flops;
+    if (reset) { c->prof_ms = 0; c->prof_launches = 0; c->prof_flops = 0; }
+    return TMAT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// Handle state of libtmat_hip.so.
+#pragma once
+#include "tmat_internal.h"
+
+#include <map>
+
+namespace tmat {
+
+struct DownBlock {
+    int cin = 0, cout = 0;
+    float *dw[2] = {nullptr, nullptr};      // [9][C]
+    float *pw[2] = {nullptr, nullptr};      // [Cin][Cout]
+    float *scale[2] = {nullptr, nullptr}, *shift[2] = {nullptr, nullptr};
+    float *res_w = nullptr, *res_b = nullptr;
+};
+struct UpBlock {
+    int cin = 0, cout = 0;
+    float *ct[2] = {nullptr, nullptr};      // conv-form taps [9][Cin][Cout]
+    float *scale[2] = {nullptr, nullptr}, *shift[2] = {nullptr, nullptr};
+    float *res_w = nullptr, *res_b = nullptr;
+};
+struct ProfEv { hipEvent_t e0, e1; double flops; };
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int patch = 0, max_patches = 0;
+    int f0 = 0, f_last = 0;
+    float *stem_w = nullptr, *stem_scale = nullptr, *stem_shift = nullptr;
+    std::vector<DownBlock> down;
+    std::vector<UpBlock> up;
+    float *final_w = nullptr;
+    float final_b = 0.f;
+    std::vector<void *> owned;              // weight allocations
+    float *buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    float *patch_in = nullptr, *patch_out = nullptr;
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    double *win1d = nullptr;
+    std::vector<double> win_host;
+    // profiling of the dominant kernel family
+    bool prof_on = false;
+    std::vector<ProfEv> ev_open;
+    std::vector<hipEvent_t> ev_pool;
+    double prof_ms = 0, prof_flops = 0;
+    int64_t prof_launches = 0;
+};
+
+int unet_forward_dev(Ctx *c, const float *X, int n, float *Y);
+int predict_smooth_dev(Ctx *c, const float *x_dev, int n, int hh, int ww, double *pred_dev);
+
+// numpy's pairwise summation of a contiguous f64 vector (np.add.reduce / np.mean inner loop):
+// 8 interleaved partial sums on blocks <= 128, recursive halves (rounded down to a multiple of 8) above.
+inline double numpy_pairwise_sum(const double *a, long n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (long i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        long i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    long n2 = n / 2;
+    n2 -= n2 % 8;
+    return numpy_pairwise_sum(a, n2) + numpy_pairwise_sum(a + n2, n - n2);
+}
+
+}  // namespace tmat

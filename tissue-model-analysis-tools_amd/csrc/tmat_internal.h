@@ -1,0 +1,54 @@
+// Internal declarations shared by the translation units of libtmat_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+namespace tmat {
+
+void set_error(const std::string &msg);
+bool hip_ok(hipError_t e, const char *what);
+#define TMAT_HIP(call) do { if (!::tmat::hip_ok((call), #call)) return TMAT_E_HIP; } while (0)
+
+// ---- UNet layer launchers (unet_kernels.hip); all tensors NHWC f32 on device ----------------
+struct ConvArgs {
+    const float *in;      // stored tensor (N, h, w, Cin)
+    int N, h, w, Cin;
+    int up;               // logical input = nearest-upsample^up of the stored tensor
+    int relu_in;          // relu applied on load
+    int ksize;            // 1 or 3
+    int stride;           // 1, or 2 with ksize 1 (TF SAME 1x1 s2 samples even indices)
+    const float *W;       // [ksize*ksize][Cin][Cout]
+    int Cout;
+    const float *scale;   // nullable: v = scale ? fmaf(acc, scale, shift) : acc + shift
+    const float *shift;
+    const float *resid;   // nullable: v += resid[n][y >> rs][x >> rs][co]
+    int rs;
+    int relu_out;
+    float *out;           // (N, H/stride, W/stride, Cout), H = h << up
+};
+// returns false (and sets the error) on unsupported shapes
+bool launch_conv(const ConvArgs &a, hipStream_t s);
+void launch_dwconv(const float *in, int N, int H, int W, int C, int relu_in, const float *Wd, float *out, hipStream_t s);
+void launch_stem(const float *x, int N, int H, int W, const float *Ws, int Cout, const float *scale,
+                 const float *shift, float *out, hipStream_t s);
+void launch_maxpool_add(const float *p2, int N, int H, int W, int C, const float *r, float *out, hipStream_t s);
+void launch_final(const float *S, int N, int h, int w, int C, const float *Wf, float bias, float *out, hipStream_t s);
+
+// ---- tiling / blending (blend_kernels.hip) -------------------------------------------------
+// x: (n, hh, ww) f32; padval[n]; patches out: (n, 8, na_g, nb_g, ws, ws)
+struct TileGeom {
+    int hh, ww;     // image
+    int ws, step, aug;
+    int Hp, Wp;     // padded
+    int na[2], nb[2];   // tile counts for even (k=0,2) / odd (k=1,3) rotations
+    int tiles_per_img;  // sum over 8 orientations
+    int tile_off[8];    // first tile index of orientation g within the image
+};
+TileGeom make_geom(int hh, int ww, int ws);
+void launch_minmax_f32(const float *x, int n, size_t per, float *mn, float *mx, hipStream_t s);
+void launch_extract_tiles(const float *x, const float *padval, int n, const TileGeom &g, float *patches, hipStream_t s);
+void launch_blend(const float *pred_patches, const double *win1d, int n, const TileGeom &g, double *out, hipStream_t s);
+
+}  // namespace tmat

@@ -1,0 +1,133 @@
+"""ctypes binding of libtmat_hip.so (include/tmat.h).
+
+The HIP library is the product path.  There is no CPU fallback: if the shared object is missing
+or no MI355X is visible, loading / `create()` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("TMAT_HIP_LIB", _HERE / "libtmat_hip.so"))
+
+_lib = None
+
+
+class TmatError(RuntimeError):
+    pass
+
+
+class Row(C.Structure):
+    _fields_ = [("index", C.c_int64), ("count", C.c_int64), ("total_px", C.c_double), ("avg_px", C.c_double)]
+
+
+def lib():
+    """Load libtmat_hip.so once; raise loudly when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise TmatError(
+            f"{LIB_PATH} not found: build it with `python tools/build.py` "
+            "(hipcc --offload-arch=gfx950). tmat_amd has no CPU fallback.")
+    L = C.CDLL(str(LIB_PATH))
+    vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    L.tmat_last_error.restype = C.c_char_p
+    L.tmat_version.restype = i
+    L.tmat_create.argtypes = [i, vp, sz, i, C.POINTER(vp)]
+    L.tmat_destroy.argtypes = [vp]
+    L.tmat_destroy.restype = None
+    L.tmat_sync.argtypes = [vp]
+    L.tmat_unet_predict.argtypes = [vp, vp, i, vp]
+    L.tmat_predict_smooth.argtypes = [vp, vp, i, i, i, vp]
+    L.tmat_segment_batch.argtypes = [vp, vp, i, i, i, f, vp]
+    L.tmat_postprocess_batch.argtypes = [vp, vp, i, i, i, i, vp]
+    L.tmat_dmt_graph.argtypes = [vp, vp, i, i, f, f, vp, i, vp, i, C.POINTER(i), C.POINTER(i)]
+    L.tmat_morse_stats.argtypes = [vp, i, vp, i, i, i, i, i, i, i, vp, C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double), vp, i]
+    L.tmat_analyze_batch_dev.argtypes = [vp, vp, i, i, i, f, i, f, f, i, i, i, i, C.c_int64, vp]
+    L.tmat_analyze_batch.argtypes = [vp, vp, i, i, i, f, i, f, f, i, i, i, i, C.c_int64, vp]
+    L.tmat_dev_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+    L.tmat_dev_free.argtypes = [vp, vp]
+    L.tmat_dev_upload.argtypes = [vp, vp, vp, sz]
+    L.tmat_prof_enable.argtypes = [vp, i]
+    L.tmat_prof_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), i]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if name not in ("tmat_last_error", "tmat_destroy"):
+            fn.restype = i
+    _lib = L
+    return L
+
+
+EXPORTS = [
+    "tmat_last_error", "tmat_version", "tmat_create", "tmat_destroy", "tmat_sync", "tmat_unet_predict",
+    "tmat_predict_smooth", "tmat_segment_batch", "tmat_postprocess_batch", "tmat_dmt_graph", "tmat_morse_stats",
+    "tmat_analyze_batch_dev", "tmat_analyze_batch", "tmat_dev_alloc", "tmat_dev_free", "tmat_dev_upload",
+    "tmat_prof_enable", "tmat_prof_read",
+]
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().tmat_last_error()
+        raise TmatError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Handle:
+    """Owns one tmat_handle (one HIP device + stream + resident weights)."""
+
+    def __init__(self, weights_blob: bytes, device_id: int = 0, max_patches: int = 0):
+        L = lib()
+        self._h = C.c_void_p()
+        self._blob = weights_blob
+        buf = (C.c_char * len(weights_blob)).from_buffer_copy(weights_blob)
+        check(L.tmat_create(device_id, C.cast(buf, C.c_void_p), len(weights_blob), max_patches, C.byref(self._h)),
+              "tmat_create")
+
+    @property
+    def raw(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().tmat_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- stage entry points --------------------------------------------------------------
+    def unet_predict(self, x: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.empty_like(x)
+        check(lib().tmat_unet_predict(self._h, ptr(x), x.shape[0], ptr(y)), "tmat_unet_predict")
+        return y
+
+    def predict_smooth(self, x: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, np.float32)
+        single = x.ndim == 2
+        xb = x[None] if single else x
+        out = np.empty(xb.shape, np.float64)
+        check(lib().tmat_predict_smooth(self._h, ptr(xb), xb.shape[0], xb.shape[1], xb.shape[2], ptr(out)),
+              "tmat_predict_smooth")
+        return out[0] if single else out
+
+    def prof_enable(self, on=True):
+        check(lib().tmat_prof_enable(self._h, int(on)), "tmat_prof_enable")
+
+    def prof_read(self, reset=True):
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        check(lib().tmat_prof_read(self._h, C.byref(ms), C.byref(n), C.byref(fl), int(reset)), "tmat_prof_read")
+        return ms.value, n.value, fl.value
