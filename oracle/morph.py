@@ -1,0 +1,289 @@
+"""oracle/morph.py -- TEST INFRASTRUCTURE ONLY.  Never imported by the product path.
+
+CPU restatement (numpy + scipy.ndimage) of the pixel stages of analyze_img's 2-D branch
+(reference scripts/compute_branches.py:309-361) and of transforms.filter_branch_seg_mask
+(reference fl_tissue_model_tools/transforms.py:209-288, 306-361).
+
+The arithmetic of most of these stages lives in third-party packages that are NOT in
+/root/reference: opencv-python 4.9 (cv2.resize) and scikit-image 0.22.0 (rescale_intensity,
+median, label, regionprops.perimeter, skeletonize, medial_axis, resize), which are themselves
+thin layers over scipy.ndimage for everything except the thinning loops.  Each function cites
+the call site and restates the published algorithm.  Pins:
+  * skeletonize / medial_axis / perimeter / label / filter_branch_seg_mask: golden vectors made
+    by running the reference's transforms.py + scikit-image 0.18.3 (the copy in /opt/conda)
+    -> tests/golden/filter.npz (tools/make_goldens.py filter);
+  * medial_axis tie-break follows 0.18.3's RandomState(0) (0.22.0 is unseeded, i.e. the
+    reference itself is not run-to-run deterministic there; SURVEY.md hard part 4);
+  * cv2 Lanczos4: "parity unpinned" (no copy of OpenCV in this environment).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+from scipy import ndimage as ndi
+
+# ------------------------------------------------------------------------------------------
+# a1: cv2.resize(img, (w, h), interpolation=cv2.INTER_LANCZOS4)   compute_branches.py:309-312
+# ------------------------------------------------------------------------------------------
+_S45 = 0.70710678118654752440084436210485
+_CS = [(1, 0), (-_S45, -_S45), (0, 1), (_S45, -_S45), (-1, 0), (_S45, _S45), (0, -1), (-_S45, _S45)]
+
+
+def lanczos4_coeffs(x: float) -> np.ndarray:
+    """OpenCV interpolateLanczos4 (imgproc/resize.cpp): 8 taps for fractional offset x, float32."""
+    x = np.float32(x)
+    y0 = -(float(x) + 3) * math.pi * 0.25
+    s0, c0 = math.sin(y0), math.cos(y0)
+    co = np.zeros(8, np.float32)
+    s = np.float32(0)
+    for i in range(8):
+        y0_ = np.float32(x + np.float32(3 - i))
+        if abs(float(y0_)) >= 1e-6:
+            y = -float(y0_) * math.pi * 0.25
+            co[i] = np.float32((_CS[i][0] * s0 + _CS[i][1] * c0) / (y * y))
+        else:
+            co[i] = np.float32(1e30)
+        s = np.float32(s + co[i])
+    inv = np.float32(np.float32(1.0) / s)
+    return (co * inv).astype(np.float32)
+
+
+def _axis_table(n_src: int, n_dst: int):
+    scale = 1.0 / (float(n_dst) / float(n_src))
+    idx = np.zeros((n_dst, 8), np.int64)
+    co = np.zeros((n_dst, 8), np.float32)
+    for d in range(n_dst):
+        fx = np.float32((d + 0.5) * scale - 0.5)
+        sx = int(math.floor(float(fx)))
+        fx = np.float32(fx - np.float32(sx))
+        co[d] = lanczos4_coeffs(fx)
+        idx[d] = np.clip(np.arange(sx - 3, sx + 5), 0, n_src - 1)
+    return idx, co
+
+
+def lanczos4_resize_u16(img: np.ndarray, out_hw) -> np.ndarray:
+    """u16 (H, W) -> u16 (h, w): separable 8-tap Lanczos4, replicate border, f32 accumulate
+    left-to-right (no FMA), horizontal then vertical, round-half-even + saturate."""
+    H, W = img.shape
+    h, w = out_hw
+    xi, xc = _axis_table(W, w)
+    yi, yc = _axis_table(H, h)
+    src = img.astype(np.float32)
+    tmp = np.zeros((H, w), np.float32)
+    for k in range(8):
+        tmp = (tmp + src[:, xi[:, k]] * xc[None, :, k]).astype(np.float32)
+    out = np.zeros((h, w), np.float32)
+    for k in range(8):
+        out = (out + tmp[yi[:, k], :] * yc[:, k, None]).astype(np.float32)
+    return np.clip(np.rint(out), 0, 65535).astype(np.uint16)
+
+
+def target_shape(shape, ratio: float):
+    """tuple(np.round(np.multiply(img.shape[:2], ds_ratio)).astype(int))   :309-311"""
+    return tuple(int(v) for v in np.round(np.multiply(shape[:2], ratio)).astype(int))
+
+
+# ------------------------------------------------------------------------------------------
+# a2 / a17: skimage.exposure.rescale_intensity(img, out_range=(lo, hi))        :316, :419
+# ------------------------------------------------------------------------------------------
+def rescale_intensity(img: np.ndarray, out_range) -> np.ndarray:
+    """integer input -> float64 arithmetic; float32 input -> float32 arithmetic (scalars are weak)."""
+    imin, imax = float(img.min()), float(img.max())
+    omin, omax = float(out_range[0]), float(out_range[1])
+    if np.issubdtype(img.dtype, np.floating):
+        ft = img.dtype.type
+        x = np.clip(img, ft(imin), ft(imax))
+        if imin != imax:
+            x = (x - ft(imin)) / ft(imax - imin)
+            return x * ft(omax - omin) + ft(omin)
+        return np.clip(x, ft(omin), ft(omax))
+    x = np.clip(img.astype(np.float64), imin, imax)
+    if imin != imax:
+        x = (x - imin) / (imax - imin)
+        return x * (omax - omin) + omin
+    return np.clip(x, omin, omax)
+
+
+# ------------------------------------------------------------------------------------------
+# a12: filter_branch_seg_mask                                             transforms.py:306-361
+# ------------------------------------------------------------------------------------------
+DISK2 = np.array([[0, 0, 1, 0, 0], [0, 1, 1, 1, 0], [1, 1, 1, 1, 1], [0, 1, 1, 1, 0], [0, 0, 1, 0, 0]], bool)
+_EIGHT = np.ones((3, 3), bool)
+_CROSS = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], bool)
+_SQRT2 = math.sqrt(2.0)
+
+
+def median13(mask: np.ndarray) -> np.ndarray:
+    """skimage.filters.median(mask, footprint=disk(2)) == ndi.median_filter(mode='nearest') (:323)."""
+    return ndi.median_filter(mask.astype(bool), footprint=DISK2, mode="nearest")
+
+
+def perimeter4(region: np.ndarray) -> float:
+    """skimage.measure.perimeter(image, neighborhood=4) (regionprops .perimeter, :328)."""
+    img = region.astype(np.uint8)
+    border = img - ndi.binary_erosion(img, _CROSS, border_value=0).astype(np.uint8)
+    code = ndi.convolve(border, np.array([[10, 2, 10], [2, 1, 2], [10, 2, 10]]), mode="constant", cval=0)
+    hist = np.bincount(code.ravel(), minlength=50)
+    n1 = int(hist[[5, 7, 15, 17, 25, 27]].sum())
+    n2 = int(hist[[21, 33]].sum())
+    n3 = int(hist[[13, 23]].sum())
+    return float(n1) + n2 * _SQRT2 + n3 * ((1 + _SQRT2) / 2)
+
+
+def zhang_lut() -> np.ndarray:
+    """256-entry table of skimage's 2-D skeletonize (Zhang-Suen): bit weights NW=1, N=2, NE=4, E=8,
+    SE=16, S=32, SW=64, W=128; value 1: removable in the first sub-iteration only, 2: second only,
+    3: both, 0: keep."""
+    lut = np.zeros(256, np.uint8)
+    for idx in range(256):
+        nw, n, ne, e, se, s, sw, w = [(idx >> k) & 1 for k in range(8)]
+        ring = [n, ne, e, se, s, sw, w, nw]          # P2..P9 clockwise from north
+        B = sum(ring)
+        A = sum(1 for k in range(8) if ring[k] == 0 and ring[(k + 1) % 8] == 1)
+        if 2 <= B <= 6 and A == 1:
+            if n * e * s == 0 and e * s * w == 0:
+                lut[idx] |= 1
+            if n * e * w == 0 and n * s * w == 0:
+                lut[idx] |= 2
+    return lut
+
+
+def skeletonize_zhang(mask: np.ndarray) -> np.ndarray:
+    """skimage.morphology.skeletonize(mask) for 2-D input (_fast_skeletonize) (:331)."""
+    lut = zhang_lut()
+    sk = np.pad(mask.astype(np.uint8), 1)
+    wts = np.array([[1, 2, 4], [128, 0, 8], [64, 32, 16]])
+    while True:
+        removed = False
+        for first in (True, False):
+            code = ndi.correlate(sk, wts, mode="constant", cval=0)
+            val = lut[code]
+            kill = (sk > 0) & ((val == 3) | ((val == 1) if first else (val == 2)))
+            if kill.any():
+                removed = True
+                sk = np.where(kill, 0, sk).astype(np.uint8)
+        if not removed:
+            break
+    return sk[1:-1, 1:-1].astype(bool)
+
+
+def skeleton_components(skel: np.ndarray):
+    """nx_graph_from_binary_skeleton (transforms.py:209-288) reduced to what
+    filter_branch_seg_mask needs: 8-connected components of the skeleton and, per component,
+    whether any node has graph degree > 2 (degree = number of 8-neighbours on the skeleton)."""
+    deg = ndi.correlate(skel.astype(np.uint8), np.array([[1, 1, 1], [1, 0, 1], [1, 1, 1]]), mode="constant")
+    fork = skel & (deg > 2)
+    lab, n = ndi.label(skel, _EIGHT)
+    has_fork = np.zeros(n + 1, bool)
+    has_fork[np.unique(lab[fork])] = True
+    return lab, n, has_fork
+
+
+def filter_branch_seg_mask(mask: np.ndarray, use_median: bool = True, remove_isolated: bool = True) -> np.ndarray:
+    """transforms.py:306-361 (returns the filtered bool mask)."""
+    mask = mask.astype(bool)
+    if use_median:
+        mask = median13(mask)
+    else:
+        mask = mask.copy()
+    lab, n = ndi.label(mask, _EIGHT)
+    circ = np.zeros(n + 1)
+    for i, sl in enumerate(ndi.find_objects(lab), start=1):
+        reg = lab[sl] == i
+        per = perimeter4(reg)
+        circ[i] = 4 * np.pi * int(reg.sum()) / (per ** 2 + 1e-7)
+    skel = skeletonize_zhang(mask)
+    slab, sn, has_fork = skeleton_components(skel)
+    remove = np.zeros(n + 1, bool)
+    for c in range(1, sn + 1):
+        ys, xs = np.nonzero(slab == c)
+        lbl = lab[ys[0], xs[0]]
+        if (remove_isolated and not has_fork[c]) or circ[lbl] > 0.8:
+            remove[lbl] = True
+    mask[remove[lab]] = False
+    return mask
+
+
+# ------------------------------------------------------------------------------------------
+# a14: skimage.morphology.medial_axis(mask, return_distance=True)        compute_branches.py:340
+# ------------------------------------------------------------------------------------------
+def _pattern_of(index):
+    return np.array([[index & 1, index & 2, index & 4], [index & 8, index & 16, index & 32],
+                     [index & 64, index & 128, index & 256]], bool)
+
+
+_MA_TABLE = None
+
+
+def medial_axis_table():
+    global _MA_TABLE
+    if _MA_TABLE is None:
+        center = (np.arange(512) & 16).astype(bool)
+        cond2 = np.array([ndi.label(_pattern_of(i), _EIGHT)[1] != ndi.label(_pattern_of(i & ~16), _EIGHT)[1]
+                          for i in range(512)])
+        cond3 = np.array([np.sum(_pattern_of(i)) < 3 for i in range(512)])
+        _MA_TABLE = (center & (cond2 | cond3)).astype(np.uint8)
+    return _MA_TABLE
+
+
+def medial_axis(mask: np.ndarray):
+    """(skeleton bool, distance f64).  Ordered one-pass thinning by
+    lexsort((tiebreak, corner_score, distance)); tie-break RandomState(0).permutation (0.18.3)."""
+    m = mask.astype(bool)
+    table = medial_axis_table()
+    dist = ndi.distance_transform_edt(m)
+    wts = np.array([[1, 2, 4], [8, 16, 32], [64, 128, 256]])
+    code = ndi.correlate(m.astype(np.int32), wts, mode="constant", cval=0)
+    corner_tab = np.array([9 - bin(i).count("1") for i in range(512)])
+    corner = corner_tab[code]
+    ii, jj = np.nonzero(m)
+    nfg = len(ii)
+    tiebreak = np.random.RandomState(0).permutation(np.arange(nfg))
+    order = np.lexsort((tiebreak, corner[m], dist[m]))
+    res = np.pad(m.astype(np.uint8), 1)
+    for k in order:
+        i, j = ii[k] + 1, jj[k] + 1
+        acc = (16 + res[i - 1, j - 1] + 2 * res[i - 1, j] + 4 * res[i - 1, j + 1] + 8 * res[i, j - 1] + 32 * res[i, j + 1]
+               + 64 * res[i + 1, j - 1] + 128 * res[i + 1, j] + 256 * res[i + 1, j + 1])
+        res[i, j] = table[acc]
+    return res[1:-1, 1:-1].astype(bool), dist
+
+
+# ------------------------------------------------------------------------------------------
+# a15: centre-line weighting                                         compute_branches.py:341-344
+# ------------------------------------------------------------------------------------------
+def centerline_weight(pred: np.ndarray, mask: np.ndarray):
+    skel, dist = medial_axis(mask)
+    cdt = ndi.distance_transform_edt(np.logical_not(skel))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rel = dist / (dist + cdt)
+    return pred * rel, skel, dist
+
+
+# ------------------------------------------------------------------------------------------
+# a16: skimage.transform.resize(order=1, preserve_range=True, anti_aliasing=True)      :351-357
+# ------------------------------------------------------------------------------------------
+def dsamp_shape(shape, width=384):
+    """np.multiply(img.shape[-2:], W / img.shape[-1]).round().astype(int)   :218-222"""
+    return tuple(int(v) for v in np.multiply(shape[-2:], width / shape[-1]).round().astype(int))
+
+
+def resize_aa(img: np.ndarray, out_shape) -> np.ndarray:
+    """scikit-image >= 0.19 resize: gaussian_filter(sigma=(f-1)/2, mode='mirror') then
+    ndi.zoom(order=1, mode='mirror', grid_mode=True), clipped to the input range.  f64 in/out."""
+    img = img.astype(np.float64)
+    factors = np.divide(img.shape, out_shape)
+    sigma = np.maximum(0, (factors - 1) / 2)
+    filt = ndi.gaussian_filter(img, sigma, cval=0, mode="mirror")
+    out = ndi.zoom(filt, [1 / f for f in factors], order=1, mode="mirror", cval=0, grid_mode=True)
+    return np.clip(out, img.min(), img.max())
+
+
+def postprocess(pred: np.ndarray, ds_width: int = 384):
+    """compute_branches.py:334-357 without a well mask: (field f32 (fh, ds_width), seg mask, skeleton)."""
+    seg = pred > 0.5
+    seg = filter_branch_seg_mask(seg)
+    weighted, skel, _ = centerline_weight(pred, seg.astype(float))
+    field = resize_aa(weighted, dsamp_shape(pred.shape, ds_width)).astype(np.float32)
+    return field, seg, skel

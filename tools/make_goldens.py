@@ -63,6 +63,172 @@ def gen_blend():
     print("blend.npz", {k: getattr(v, "shape", None) for k, v in out.items()})
 
 
+
+
+# --------------------------------------------------------------------------------------------
+# filter group: run under /opt/conda/bin/python3.9 (scikit-image 0.18.3, networkx 2.6.3)
+# --------------------------------------------------------------------------------------------
+def _fixture_masks():
+    from scipy import ndimage as ndi
+    import tifffile
+    masks = {}
+    for name, fn in (("d5", "D5_1_ZProj_002_mask.tif"), ("m1", "mask.tif")):
+        a = tifffile.imread(str(REF / "notebooks" / "topology" / "sample_data" / fn))
+        if a.ndim == 3:
+            a = a[..., 0]
+        yy = (np.arange(640) * a.shape[0] / 640).astype(int)
+        xx = (np.arange(640) * a.shape[1] / 640).astype(int)
+        masks[name] = a[yy][:, xx] > 0
+    rs = np.random.RandomState(21)
+    masks["blobs"] = ndi.gaussian_filter(rs.normal(size=(200, 300)), 4) > 0.03
+    masks["noise"] = rs.uniform(size=(96, 128)) > 0.45
+    small = np.zeros((64, 80), bool)
+    small[2, 2] = True                       # single pixel
+    small[5:7, 5:7] = True                   # 2x2 block
+    small[10, 10:40] = True                  # thin line, no fork
+    small[20:50, 20:23] = True; small[33:36, 10:60] = True   # thick cross (forks)
+    yy, xx = np.mgrid[:64, :80]
+    small |= ((yy - 40) ** 2 + (xx - 66) ** 2) <= 81      # disc: circularity > 0.8
+    masks["small"] = small
+    masks["empty"] = np.zeros((40, 40), bool)
+    masks["full"] = np.ones((40, 48), bool)
+    return masks
+
+
+def gen_filter():
+    from scipy import ndimage as ndi
+    from skimage.morphology import skeletonize, medial_axis, disk
+    from skimage.measure import label, regionprops
+    from fl_tissue_model_tools import transforms
+
+    out = {}
+    for name, m in _fixture_masks().items():
+        out[name + "_shape"] = np.array(m.shape)
+        out[name + "_mask"] = np.packbits(m)
+        med = ndi.median_filter(m, footprint=disk(2), mode="nearest")
+        out[name + "_median"] = np.packbits(med)
+        out[name + "_skel"] = np.packbits(skeletonize(med))
+        lab = label(med, connectivity=2)
+        props = regionprops(lab)
+        out[name + "_nlabels"] = np.int64(lab.max())
+        out[name + "_areas"] = np.array([p.area for p in props], np.int64)
+        out[name + "_perims"] = np.array([p.perimeter for p in props], np.float64)
+        # the reference's own function (median applied by hand: skimage 0.18 names the kwarg selem)
+        filt = transforms.filter_branch_seg_mask(med.copy(), None)
+        out[name + "_filtered"] = np.packbits(filt.astype(bool))
+        filt_keep = transforms.filter_branch_seg_mask(med.copy(), None, False)
+        out[name + "_filtered_keepiso"] = np.packbits(filt_keep.astype(bool))
+        sk, dist = medial_axis(filt.astype(float), return_distance=True)
+        out[name + "_ma_skel"] = np.packbits(sk)
+        out[name + "_ma_dist_sha"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(dist).tobytes()).digest(), np.uint8)
+    np.savez_compressed(GOLD / "filter.npz", **out)
+    print("filter.npz", len(out), "arrays,", sum(v.nbytes for v in out.values()), "bytes")
+
+
+# --------------------------------------------------------------------------------------------
+# dmt / morse groups: run under /opt/conda/bin/python3.9 (numpy 1.26.4 = the reference's pin)
+# --------------------------------------------------------------------------------------------
+def synth_field(seed, shape):
+    """deterministic ridge-like f32 field in 0..255 (regenerated by the tests from the seed)."""
+    from scipy import ndimage as ndi
+    rs = np.random.RandomState(seed)
+    a = ndi.gaussian_filter(rs.normal(size=shape), 3.0)
+    b = np.exp(-(a / a.std()) ** 2 * 6.0)                 # ridges along the zero set of a
+    b *= ndi.gaussian_filter(rs.uniform(size=shape), 6.0) > 0.5
+    b = ndi.gaussian_filter(b, 1.0)
+    b = (b - b.min()) / (b.max() - b.min() + 1e-12) * 255.0
+    return b.astype(np.float32)
+
+
+def real_fields():
+    """384^2 vesselness-like fields from the two binary vessel masks the reference ships
+    (notebooks/topology/sample_data/*.tif), stored as float16 (exact in f32)."""
+    from scipy import ndimage as ndi
+    import tifffile
+    out = {}
+    for name, fn in (("d5", "D5_1_ZProj_002_mask.tif"), ("m1", "mask.tif")):
+        a = tifffile.imread(str(REF / "notebooks" / "topology" / "sample_data" / fn))
+        if a.ndim == 3:
+            a = a[..., 0]
+        m = (a > 0).astype(np.float64)
+        f = np.divide(m.shape, (384, 384))
+        m = ndi.gaussian_filter(m, (f - 1) / 2, mode="mirror")
+        m = ndi.zoom(m, 384 / np.array(m.shape), order=1, mode="mirror", grid_mode=True)
+        m = np.clip(ndi.gaussian_filter(m, 1.2) * 1.3, 0, 1) * 255.0
+        out[name] = m.astype(np.float16)
+    return out
+
+
+DMT_SYNTH = [("s96", 31, (96, 96)), ("s_rect", 32, (72, 96)), ("s160", 33, (160, 160))]
+DELTAS = [(5.0, 10.0), (2.0, 4.0), (0.5, 0.0)]
+
+
+def gen_dmt():
+    from fl_tissue_model_tools.dmtgraph import compute_dmt_graph
+    out = {}
+    fields = {n: synth_field(seed, shape) for n, seed, shape in DMT_SYNTH}
+    for n, f in real_fields().items():
+        out["field_" + n] = f
+        fields[n] = f.astype(np.float32)
+    fields["zero"] = np.zeros((24, 24), np.float32)
+    fields["const"] = np.full((24, 30), 7.0, np.float32)
+    one = np.zeros((16, 16), np.float32); one[5, 9] = 200.0
+    fields["single"] = one
+    q = np.round(synth_field(34, (64, 64)) / 16.0) * 16.0      # heavy ties
+    fields["ties"] = q.astype(np.float32)
+    out["field_ties"] = fields["ties"].astype(np.float16)
+    for name, f in fields.items():
+        for d1, d2 in DELTAS:
+            V, E = compute_dmt_graph(f, d1, d2)
+            key = f"{name}_{d1}_{d2}"
+            out[key + "_V"] = V.astype(np.int32)
+            out[key + "_E"] = E.astype(np.int32)
+            print(key, V.shape, E.shape, flush=True)
+    np.savez_compressed(GOLD / "dmt.npz", **out)
+    print("dmt.npz", sum(v.nbytes for v in out.values()), "bytes raw")
+
+
+MORSE_CASES = [  # (delta1, delta2, smoothing, min_len, max_len, remove_isolated, use_mask)
+    (5.0, 10.0, 5, 5, None, False, False),
+    (2.0, 4.0, 5, 5, None, False, False),
+    (5.0, 10.0, 12, 12, None, False, False),
+    (0.5, 0.0, 1, 3, None, False, False),
+    (5.0, 10.0, 5, 5, None, True, False),
+    (5.0, 10.0, 5, 5, 40, False, False),
+    (5.0, 10.0, 5, 5, None, False, True),
+    (2.0, 4.0, 8, 3, 60, True, True),
+]
+
+
+def prune_mask(shape):
+    yy, xx = np.mgrid[: shape[0], : shape[1]]
+    r = min(shape) * 0.42
+    return ((yy - shape[0] / 2) ** 2 + (xx - shape[1] / 2) ** 2) > r * r
+
+
+def gen_morse():
+    from fl_tissue_model_tools.topology import MorseGraph
+    out = {}
+    fields = {n: synth_field(seed, shape) for n, seed, shape in DMT_SYNTH}
+    for n, f in real_fields().items():
+        fields[n] = f.astype(np.float32)
+    fields["zero"] = np.zeros((24, 24), np.float32)
+    for name, f in fields.items():
+        for ci, (d1, d2, sw, mn, mx, iso, um) in enumerate(MORSE_CASES):
+            pm = prune_mask(f.shape) if um else None
+            mg = MorseGraph(f, thresholds=(d1, d2), min_branch_length=mn, max_branch_length=mx,
+                            remove_isolated_branches=iso, smoothing_window=sw, pruning_mask=pm)
+            bars = np.array(mg.barcode, np.float64).reshape(-1, 2)
+            key = f"{name}_c{ci}"
+            out[key + "_bars"] = bars
+            out[key + "_count"] = np.int64(len(mg.barcode))
+            out[key + "_total"] = np.float64(mg.get_total_branch_length())
+            out[key + "_avg"] = np.float64(mg.get_average_branch_length())
+            print(key, len(mg.barcode), float(mg.get_total_branch_length()), flush=True)
+    np.savez_compressed(GOLD / "morse.npz", **out)
+
+
+
 if __name__ == "__main__":
     GOLD.mkdir(parents=True, exist_ok=True)
     _shims()
