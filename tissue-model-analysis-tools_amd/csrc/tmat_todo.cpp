@@ -5,9 +5,6 @@
 extern "C" {
 int tmat_segment_batch(tmat_handle, const uint16_t *, int, int, int, float, double *) { NOTYET("tmat_segment_batch"); }
 int tmat_postprocess_batch(tmat_handle, const double *, int, int, int, int, float *) { NOTYET("tmat_postprocess_batch"); }
-int tmat_dmt_graph(tmat_handle, const float *, int, int, float, float, int32_t *, int, int32_t *, int, int *, int *) { NOTYET("tmat_dmt_graph"); }
-int tmat_morse_stats(const int32_t *, int, const int32_t *, int, int, int, int, int, int, int, const uint8_t *, int64_t *,
-                     double *, double *, double *, int) { NOTYET("tmat_morse_stats"); }
 int tmat_analyze_batch_dev(tmat_handle, const uint16_t *, int, int, int, float, int, float, float, int, int, int, int, int64_t,
                            tmat_row *) { NOTYET("tmat_analyze_batch_dev"); }
 int tmat_analyze_batch(tmat_handle, const uint16_t *, int, int, int, float, int, float, float, int, int, int, int, int64_t,

@@ -131,3 +131,35 @@ class Handle:
         ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
         check(lib().tmat_prof_read(self._h, C.byref(ms), C.byref(n), C.byref(fl), int(reset)), "tmat_prof_read")
         return ms.value, n.value, fl.value
+
+
+# -- host-only entry points (no handle / no GPU needed) ------------------------------------------
+def dmt_graph(img: np.ndarray, delta1: float, delta2: float = 0.0, handle: "Handle | None" = None):
+    """tmat_dmt_graph: (vertices (n,2) int32 [row, col], edges (m,2) int32)."""
+    img = np.ascontiguousarray(img, np.float32)
+    R, Cc = img.shape
+    cap_v, cap_e = R * Cc + 4, 3 * R * Cc + 4
+    V = np.empty((cap_v, 2), np.int32)
+    E = np.empty((cap_e, 2), np.int32)
+    nv, ne = C.c_int(), C.c_int()
+    check(lib().tmat_dmt_graph(handle.raw if handle else None, ptr(img), R, Cc, float(delta1), float(delta2), ptr(V), cap_v,
+                               ptr(E), cap_e, C.byref(nv), C.byref(ne)), "tmat_dmt_graph")
+    return V[: nv.value].copy(), E[: ne.value].copy()
+
+
+def morse_stats(V, E, shape, smoothing_window, min_branch_length, max_branch_length=None,
+                remove_isolated_branches=False, pruning_mask=None):
+    """tmat_morse_stats: (bars (k,2) f64, count, total_px, avg_px)."""
+    V = np.ascontiguousarray(V, np.int32).reshape(-1, 2)
+    E = np.ascontiguousarray(E, np.int32).reshape(-1, 2)
+    pm = None
+    if pruning_mask is not None:
+        pm = np.ascontiguousarray(np.asarray(pruning_mask) > 0, np.uint8)
+    cap = max(len(V), 1)
+    bars = np.empty((cap, 2), np.float64)
+    cnt, tot, avg = C.c_int64(), C.c_double(), C.c_double()
+    check(lib().tmat_morse_stats(ptr(V), len(V), ptr(E), len(E), int(shape[0]), int(shape[1]), int(smoothing_window),
+                                 int(min_branch_length), int(max_branch_length or 0), int(bool(remove_isolated_branches)),
+                                 ptr(pm) if pm is not None else None, C.byref(cnt), C.byref(tot), C.byref(avg), ptr(bars), cap),
+          "tmat_morse_stats")
+    return bars[: cnt.value].copy(), cnt.value, tot.value, avg.value

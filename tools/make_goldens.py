@@ -210,8 +210,9 @@ def gen_morse():
     from fl_tissue_model_tools.topology import MorseGraph
     out = {}
     fields = {n: synth_field(seed, shape) for n, seed, shape in DMT_SYNTH}
-    for n, f in real_fields().items():
-        fields[n] = f.astype(np.float32)
+    dmt_gold = np.load(GOLD / "dmt.npz")       # real-mask fields made by gen_dmt (needs tifffile)
+    for n in ("d5", "m1"):
+        fields[n] = dmt_gold["field_" + n].astype(np.float32)
     fields["zero"] = np.zeros((24, 24), np.float32)
     for name, f in fields.items():
         for ci, (d1, d2, sw, mn, mx, iso, um) in enumerate(MORSE_CASES):
