@@ -131,22 +131,25 @@ def perimeter4(region: np.ndarray) -> float:
     return float(n1) + n2 * _SQRT2 + n3 * ((1 + _SQRT2) / 2)
 
 
+_SKEL_LUT = np.array([
+    0, 0, 0, 1, 0, 0, 1, 3, 0, 0, 3, 1, 1, 0, 1, 3, 0, 0, 0, 0, 0, 0, 0, 0, 2, 0, 2, 0, 3, 0, 3, 3,
+    0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 0, 0, 0, 3, 0, 2, 2,
+    0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+    2, 0, 0, 0, 0, 0, 0, 0, 2, 0, 0, 0, 2, 0, 0, 0, 3, 0, 0, 0, 0, 0, 0, 0, 3, 0, 0, 0, 3, 0, 2, 0,
+    0, 0, 3, 1, 0, 0, 1, 3, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1,
+    3, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+    2, 3, 1, 3, 0, 0, 1, 3, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+    2, 3, 0, 1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 3, 3, 0, 1, 0, 0, 0, 0, 2, 2, 0, 0, 2, 0, 0, 0], np.uint8)
+
+
 def zhang_lut() -> np.ndarray:
-    """256-entry table of skimage's 2-D skeletonize (Zhang-Suen): bit weights NW=1, N=2, NE=4, E=8,
-    SE=16, S=32, SW=64, W=128; value 1: removable in the first sub-iteration only, 2: second only,
-    3: both, 0: keep."""
-    lut = np.zeros(256, np.uint8)
-    for idx in range(256):
-        nw, n, ne, e, se, s, sw, w = [(idx >> k) & 1 for k in range(8)]
-        ring = [n, ne, e, se, s, sw, w, nw]          # P2..P9 clockwise from north
-        B = sum(ring)
-        A = sum(1 for k in range(8) if ring[k] == 0 and ring[(k + 1) % 8] == 1)
-        if 2 <= B <= 6 and A == 1:
-            if n * e * s == 0 and e * s * w == 0:
-                lut[idx] |= 1
-            if n * e * w == 0 and n * s * w == 0:
-                lut[idx] |= 2
-    return lut
+    """256-entry table of scikit-image's 2-D skeletonize (`_fast_skeletonize`): neighbour weights
+    NW=1, N=2, NE=4, E=8, SE=16, S=32, SW=64, W=128; value 1: removable in the first
+    sub-iteration only, 2: second only, 3: both, 0: keep.  It is NOT the textbook Zhang-Suen table
+    (corner pixels of 8-connected staircases are removable); the values were recovered from the
+    compiled function's behaviour (tools/recover_skel_lut.py) and are pinned by
+    tests/golden/filter.npz."""
+    return _SKEL_LUT
 
 
 def skeletonize_zhang(mask: np.ndarray) -> np.ndarray:
@@ -241,7 +244,7 @@ def medial_axis(mask: np.ndarray):
     nfg = len(ii)
     tiebreak = np.random.RandomState(0).permutation(np.arange(nfg))
     order = np.lexsort((tiebreak, corner[m], dist[m]))
-    res = np.pad(m.astype(np.uint8), 1)
+    res = np.pad(m.astype(np.int64), 1)
     for k in order:
         i, j = ii[k] + 1, jj[k] + 1
         acc = (16 + res[i - 1, j - 1] + 2 * res[i - 1, j] + 4 * res[i - 1, j + 1] + 8 * res[i, j - 1] + 32 * res[i, j + 1]
@@ -269,9 +272,84 @@ def dsamp_shape(shape, width=384):
     return tuple(int(v) for v in np.multiply(shape[-2:], width / shape[-1]).round().astype(int))
 
 
+def gaussian_kernel1d(sigma: float):
+    """scipy.ndimage._filters._gaussian_kernel1d(sigma, 0, radius=int(4*sigma+0.5)); exp via libm
+    (math.exp) so the C++ product can form bit-identical weights."""
+    radius = int(4.0 * float(sigma) + 0.5)
+    sigma2 = sigma * sigma
+    phi = np.array([math.exp(-0.5 / sigma2 * (x * x)) for x in range(-radius, radius + 1)], np.float64)
+    tot = 0.0
+    for v in phi:                       # numpy sums < 8 elements sequentially
+        tot += v
+    assert len(phi) < 8
+    return phi / tot
+
+
+def _mirror(i, n):
+    """scipy 'mirror' extension: d c b | a b c d | c b a"""
+    if n == 1:
+        return 0
+    p = 2 * (n - 1)
+    i %= p
+    return i if i < n else p - i
+
+
+def correlate1d_sym(a: np.ndarray, w: np.ndarray, axis: int) -> np.ndarray:
+    """scipy.ndimage.correlate1d for a symmetric odd kernel, mode='mirror':
+    out = x[l]*w[c] + sum_{j=-r..-1} (x[l+j] + x[l-j]) * w[c+j]   (outermost taps first)."""
+    r = len(w) // 2
+    a = np.moveaxis(a, axis, 0)
+    n = a.shape[0]
+    idx = lambda off: np.array([_mirror(l + off, n) for l in range(n)])
+    out = a * w[r]
+    for j in range(-r, 0):
+        out = out + (a[idx(j)] + a[idx(-j)]) * w[r + j]
+    return np.moveaxis(out, 0, axis)
+
+
+def zoom_linear_grid(a: np.ndarray, out_shape) -> np.ndarray:
+    """scipy.ndimage.zoom(a, order=1, mode='mirror', grid_mode=True) (NI_ZoomShift): source
+    coordinate (j + 0.5) * (in/out) - 0.5, weights (1 - t, 1 - (1 - t)), accumulation order
+    ((c00*wr0)*wc0 + (c01*wr0)*wc1) + (c10*wr1)*wc0 + (c11*wr1)*wc1."""
+    def axis_tab(n_in, n_out):
+        zoom = n_in / n_out
+        i0 = np.zeros(n_out, np.int64); i1 = np.zeros(n_out, np.int64)
+        w0 = np.zeros(n_out); w1 = np.zeros(n_out)
+        for j in range(n_out):
+            cc = (j + 0.5) * zoom - 0.5
+            fl = math.floor(cc)
+            t = cc - fl
+            w0[j] = 1.0 - t
+            w1[j] = 1.0 - w0[j]
+            i0[j] = _mirror(int(fl), n_in); i1[j] = _mirror(int(fl) + 1, n_in)
+        return i0, i1, w0, w1
+    r0, r1, wr0, wr1 = axis_tab(a.shape[0], out_shape[0])
+    c0, c1, wc0, wc1 = axis_tab(a.shape[1], out_shape[1])
+    t = (a[np.ix_(r0, c0)] * wr0[:, None]) * wc0[None, :]
+    t = t + (a[np.ix_(r0, c1)] * wr0[:, None]) * wc1[None, :]
+    t = t + (a[np.ix_(r1, c0)] * wr1[:, None]) * wc0[None, :]
+    t = t + (a[np.ix_(r1, c1)] * wr1[:, None]) * wc1[None, :]
+    return t
+
+
 def resize_aa(img: np.ndarray, out_shape) -> np.ndarray:
-    """scikit-image >= 0.19 resize: gaussian_filter(sigma=(f-1)/2, mode='mirror') then
-    ndi.zoom(order=1, mode='mirror', grid_mode=True), clipped to the input range.  f64 in/out."""
+    """scikit-image >= 0.19 resize(order=1, anti_aliasing=True, preserve_range=True):
+    ndi.gaussian_filter(sigma=(f-1)/2, mode='mirror') then ndi.zoom(order=1, mode='mirror',
+    grid_mode=True), clipped to the input range.  f64 in/out.  Restated tap by tap (and checked
+    against scipy itself in tests/test_oracle_morph.py) so the product can match it bit for bit."""
+    img = img.astype(np.float64)
+    factors = np.divide(img.shape, out_shape)
+    sigma = np.maximum(0, (factors - 1) / 2)
+    filt = img
+    for ax in (0, 1):
+        if sigma[ax] > 0:
+            filt = correlate1d_sym(filt, gaussian_kernel1d(float(sigma[ax])), ax)
+    out = zoom_linear_grid(filt, out_shape)
+    return np.clip(out, img.min(), img.max())
+
+
+def resize_aa_scipy(img: np.ndarray, out_shape) -> np.ndarray:
+    """the same through scipy.ndimage directly (what scikit-image calls)"""
     img = img.astype(np.float64)
     factors = np.divide(img.shape, out_shape)
     sigma = np.maximum(0, (factors - 1) / 2)
@@ -280,10 +358,10 @@ def resize_aa(img: np.ndarray, out_shape) -> np.ndarray:
     return np.clip(out, img.min(), img.max())
 
 
-def postprocess(pred: np.ndarray, ds_width: int = 384):
-    """compute_branches.py:334-357 without a well mask: (field f32 (fh, ds_width), seg mask, skeleton)."""
+def postprocess(pred: np.ndarray, out_shape):
+    """compute_branches.py:334-357 without a well mask: (field f32 out_shape, seg mask, skeleton)."""
     seg = pred > 0.5
     seg = filter_branch_seg_mask(seg)
     weighted, skel, _ = centerline_weight(pred, seg.astype(float))
-    field = resize_aa(weighted, dsamp_shape(pred.shape, ds_width)).astype(np.float32)
+    field = resize_aa(weighted, out_shape).astype(np.float32)
     return field, seg, skel

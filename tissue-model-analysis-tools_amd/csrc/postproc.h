@@ -1,0 +1,21 @@
+// host pixel stages (postproc.cpp)
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <vector>
+namespace tmat {
+void lanczos4_resize_u16(const uint16_t *img, int H, int W, int h, int w, uint16_t *out);
+void rescale01_u16(const uint16_t *img, size_t n, float *out);
+void rescale255_f32(const float *img, size_t n, float *out);
+void median13(const uint8_t *m, int H, int W, uint8_t *out);
+int label8(const uint8_t *m, int H, int W, std::vector<int32_t> &lab);
+void skeletonize_zhang(const uint8_t *m, int H, int W, uint8_t *out);
+void filter_mask(const uint8_t *mask_in, int H, int W, bool use_median, bool remove_isolated, uint8_t *out);
+void edt(const uint8_t *m, int H, int W, double *dist);
+void legacy_permutation(uint32_t seed, size_t n, std::vector<uint32_t> &perm);
+void medial_axis(const uint8_t *m, int H, int W, uint8_t *skel, double *dist);
+void resize_aa(const double *img, int H, int W, int oh, int ow, float *out);
+void postprocess_image(const double *pred, int H, int W, int oh, int ow, float *field);
+int dmt_graph_host(const float *img, int R, int C, float delta1, float delta2, int32_t *verts, int cap_v, int32_t *edges,
+                   int cap_e, int *n_verts, int *n_edges);
+}  // namespace tmat

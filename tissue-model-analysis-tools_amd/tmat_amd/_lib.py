@@ -163,3 +163,76 @@ def morse_stats(V, E, shape, smoothing_window, min_branch_length, max_branch_len
                                  ptr(pm) if pm is not None else None, C.byref(cnt), C.byref(tot), C.byref(avg), ptr(bars), cap),
           "tmat_morse_stats")
     return bars[: cnt.value].copy(), cnt.value, tot.value, avg.value
+
+
+# -- host pixel stages (csrc/postproc.cpp); exposed for stage-wise parity tests --------------------
+def host_lanczos4_u16(img, out_hw):
+    img = np.ascontiguousarray(img, np.uint16)
+    out = np.empty(out_hw, np.uint16)
+    L = lib()
+    L.tmat_host_lanczos4_u16.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    check(L.tmat_host_lanczos4_u16(ptr(img), img.shape[0], img.shape[1], out_hw[0], out_hw[1], ptr(out)), "lanczos4")
+    return out
+
+
+def host_rescale01_u16(img):
+    img = np.ascontiguousarray(img, np.uint16)
+    out = np.empty(img.shape, np.float32)
+    L = lib()
+    L.tmat_host_rescale01_u16.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    check(L.tmat_host_rescale01_u16(ptr(img), img.size, ptr(out)), "rescale01")
+    return out
+
+
+def host_rescale255_f32(img):
+    img = np.ascontiguousarray(img, np.float32)
+    out = np.empty(img.shape, np.float32)
+    L = lib()
+    L.tmat_host_rescale255_f32.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    check(L.tmat_host_rescale255_f32(ptr(img), img.size, ptr(out)), "rescale255")
+    return out
+
+
+def host_filter_mask(mask, use_median=True, remove_isolated=True):
+    m = np.ascontiguousarray(np.asarray(mask) != 0, np.uint8)
+    out = np.empty(m.shape, np.uint8)
+    L = lib()
+    L.tmat_host_filter_mask.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    check(L.tmat_host_filter_mask(ptr(m), m.shape[0], m.shape[1], int(use_median), int(remove_isolated), ptr(out)), "filter")
+    return out.astype(bool)
+
+
+def host_skeletonize(mask):
+    m = np.ascontiguousarray(np.asarray(mask) != 0, np.uint8)
+    out = np.empty(m.shape, np.uint8)
+    L = lib()
+    L.tmat_host_skeletonize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    check(L.tmat_host_skeletonize(ptr(m), m.shape[0], m.shape[1], ptr(out)), "skeletonize")
+    return out.astype(bool)
+
+
+def host_medial_axis(mask):
+    m = np.ascontiguousarray(np.asarray(mask) != 0, np.uint8)
+    sk = np.empty(m.shape, np.uint8)
+    dist = np.empty(m.shape, np.float64)
+    L = lib()
+    L.tmat_host_medial_axis.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    check(L.tmat_host_medial_axis(ptr(m), m.shape[0], m.shape[1], ptr(sk), ptr(dist)), "medial_axis")
+    return sk.astype(bool), dist
+
+
+def host_permutation(seed, n):
+    out = np.empty(n, np.uint32)
+    L = lib()
+    L.tmat_host_permutation.argtypes = [C.c_uint32, C.c_int, C.c_void_p]
+    check(L.tmat_host_permutation(seed, n, ptr(out)), "permutation")
+    return out
+
+
+def host_postprocess(pred, out_shape):
+    pred = np.ascontiguousarray(pred, np.float64)
+    out = np.empty(out_shape, np.float32)
+    L = lib()
+    L.tmat_host_postprocess.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    check(L.tmat_host_postprocess(ptr(pred), pred.shape[0], pred.shape[1], out_shape[0], out_shape[1], ptr(out)), "postprocess")
+    return out
