@@ -66,15 +66,16 @@ int tmat_predict_smooth(tmat_handle h, const float *x, int n, int hh, int ww, do
  * -> rescale_intensity(out_range=(0,1)).astype(f32) -> model.predict(auto_resample=False).
  * imgs: (n, H, W) u16; pred: (n, round(H*ds_ratio), round(W*ds_ratio)) f64.
  */
-int tmat_segment_batch(tmat_handle h, const uint16_t *imgs, int n, int H, int W, float ds_ratio, double *pred);
+int tmat_segment_batch(tmat_handle h, const uint16_t *imgs, int n, int H, int W, double ds_ratio, double *pred);
 
 /*
  * compute_branches.py:334-361 for a batch: pred > 0.5 -> filter_branch_seg_mask
  * (transforms.py:306-361) -> medial_axis + EDT centre-line weighting -> skimage resize to
- * (round(h * ds_width / w), ds_width), order 1, anti-aliased -> f32.
- * pred: (n, h, w) f64; field: (n, fh, ds_width) f32 with fh = round(h * ds_width / w).
+ * img_dsamp_res = (out_h, out_w) (compute_branches.py:218-222: round(orig_shape * 384 / orig_width)),
+ * order 1, anti-aliased -> f32.   pred: (n, h, w) f64; field: (n, out_h, out_w) f32.
+ * Round 1: these stages execute on host worker threads; `h` may be NULL.
  */
-int tmat_postprocess_batch(tmat_handle h, const double *pred, int n, int hh, int ww, int ds_width, float *field);
+int tmat_postprocess_batch(tmat_handle h, const double *pred, int n, int hh, int ww, int out_h, int out_w, float *field);
 
 /*
  * fl_tissue_model_tools.dmtgraph.compute_dmt_graph(img, delta1, delta2) (reference
@@ -114,13 +115,13 @@ typedef struct tmat_row {
  * min_branch_length_px, max_branch_length_px (<=0: none), remove_isolated: as computed at
  * compute_branches.py:401-426.
  */
-int tmat_analyze_batch_dev(tmat_handle h, const uint16_t *imgs_dev, int n, int H, int W, float ds_ratio,
+int tmat_analyze_batch_dev(tmat_handle h, const uint16_t *imgs_dev, int n, int H, int W, double ds_ratio,
                            int ds_width, float graph_thresh_1, float graph_thresh_2, int smoothing_window_px,
                            int min_branch_length_px, int max_branch_length_px, int remove_isolated,
                            int64_t first_index, tmat_row *rows);
 
 /* host-pointer convenience wrapper of the above (uploads imgs first) */
-int tmat_analyze_batch(tmat_handle h, const uint16_t *imgs, int n, int H, int W, float ds_ratio, int ds_width,
+int tmat_analyze_batch(tmat_handle h, const uint16_t *imgs, int n, int H, int W, double ds_ratio, int ds_width,
                        float graph_thresh_1, float graph_thresh_2, int smoothing_window_px,
                        int min_branch_length_px, int max_branch_length_px, int remove_isolated,
                        int64_t first_index, tmat_row *rows);
@@ -129,6 +130,25 @@ int tmat_analyze_batch(tmat_handle h, const uint16_t *imgs, int n, int H, int W,
 int tmat_dev_alloc(tmat_handle h, size_t bytes, void **dev_ptr);
 int tmat_dev_free(tmat_handle h, void *dev_ptr);
 int tmat_dev_upload(tmat_handle h, void *dev_dst, const void *host_src, size_t bytes);
+
+/*
+ * Host pixel stages, exposed one by one for stage-wise parity tests (csrc/postproc.cpp).  They are
+ * the implementation the batch entry points above use for these stages -- not a fallback.
+ *   lanczos4: cv2.resize(INTER_LANCZOS4) on u16 (compute_branches.py:312); rescale01: rescale_intensity
+ *   (0,1) of an integer image -> f32 (:316); rescale255: rescale_intensity (0,255) in f32 (:419);
+ *   filter_mask: transforms.filter_branch_seg_mask (transforms.py:306-361); skeletonize: skimage
+ *   skeletonize (transforms.py:331); medial_axis: skimage medial_axis(return_distance=True)
+ *   (compute_branches.py:340); permutation: numpy RandomState(seed).permutation(arange(n));
+ *   postprocess: compute_branches.py:334-357 for one image.
+ */
+int tmat_host_lanczos4_u16(const uint16_t *img, int H, int W, int h, int w, uint16_t *out);
+int tmat_host_rescale01_u16(const uint16_t *img, size_t n, float *out);
+int tmat_host_rescale255_f32(const float *img, size_t n, float *out);
+int tmat_host_filter_mask(const uint8_t *mask, int H, int W, int use_median, int remove_isolated, uint8_t *out);
+int tmat_host_skeletonize(const uint8_t *mask, int H, int W, uint8_t *out);
+int tmat_host_medial_axis(const uint8_t *mask, int H, int W, uint8_t *skel, double *dist);
+int tmat_host_permutation(uint32_t seed, int n, uint32_t *out);
+int tmat_host_postprocess(const double *pred, int H, int W, int out_h, int out_w, float *field);
 
 /*
  * Timing hook for bench.py's roofline line: accumulated HIP-event time (ms) and launch count of

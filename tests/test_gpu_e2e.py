@@ -1,0 +1,84 @@
+"""GPU parity, whole path through the C-ABI: uint16 images -> (count, total, average) rows and every
+intermediate boundary (segment, postprocess) against the oracle, bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(graph_thresh_1=5, graph_thresh_2=10, graph_smoothing_window=12, min_branch_length=12,
+           remove_isolated_branches=False)
+
+
+@pytest.fixture(scope="module")
+def images():
+    from tmat_amd import synth
+    return np.stack([synth.synth_image(i, 512, n_vessels=12, scale=1.0) for i in range(2)])
+
+
+@pytest.fixture(scope="module")
+def oracle_runs(weights, images):
+    """oracle (exact-arithmetic UNet) results per image, computed once"""
+    from oracle import pipeline
+    return [pipeline.analyze_image(img, weights, CFG, 500.0, return_intermediates=True) for img in images]
+
+
+def test_segment_batch_bitexact(handle, images, oracle_runs):
+    from tmat_amd import _lib
+    n, H, W = images.shape
+    pred = np.empty((n, 320, 320), np.float64)
+    _lib.check(_lib.lib().tmat_segment_batch(handle.raw, _lib.ptr(images), n, H, W, 0.625, _lib.ptr(pred)), "segment")
+    for i in range(n):
+        ref = oracle_runs[i][1]["pred"]
+        assert np.array_equal(pred[i].view(np.uint64), ref.view(np.uint64)), f"image {i}"
+
+
+def test_postprocess_batch_bitexact(handle, images, oracle_runs):
+    from tmat_amd import _lib
+    pred = np.stack([r[1]["pred"] for r in oracle_runs])
+    field = np.empty((len(pred), 384, 384), np.float32)
+    _lib.check(_lib.lib().tmat_postprocess_batch(handle.raw, _lib.ptr(pred), len(pred), 320, 320, 384, 384, _lib.ptr(field)), "post")
+    for i in range(len(pred)):
+        assert np.array_equal(field[i].view(np.uint32), oracle_runs[i][1]["field"].view(np.uint32))
+
+
+def test_analyze_batch_rows_match_oracle(handle, images, oracle_runs):
+    from tmat_amd import branches
+    rows = branches.analyze_batch(handle, images, CFG, 500.0, first_index=7)
+    assert sum(r[1] for r in rows) > 0, "test images should produce branches"
+    for i, (idx, cnt, tot, avg) in enumerate(rows):
+        n0, tot0, avg0 = oracle_runs[i][0]
+        assert idx == 7 + i
+        assert cnt == n0, f"image {i}: count {cnt} != {n0}"
+        assert tot == tot0 and avg == avg0, f"image {i}: {tot} {avg} vs {tot0} {avg0}"
+
+
+def test_analyze_nonsquare_and_degenerate(handle, weights):
+    from oracle import pipeline
+    from tmat_amd import branches, synth
+    img = synth.synth_image(11, 320, n_vessels=12)[:256]          # (256, 320)
+    flat = np.full((256, 320), 1000, np.uint16)                    # constant image
+    zero = np.zeros((256, 320), np.uint16)
+    batch = np.stack([img, flat, zero])
+    rows = branches.analyze_batch(handle, batch, CFG, 300.0)
+    for i in range(3):
+        n0, tot0, avg0 = pipeline.analyze_image(batch[i], weights, CFG, 300.0)
+        assert rows[i][1] == n0 and rows[i][2] == tot0 and rows[i][3] == avg0
+
+
+def test_mirror_api(handle, weights, images, oracle_runs):
+    """the reference-named Python surface drives the same kernels"""
+    from oracle import pipeline, morph
+    from tmat_amd import models, smooth_tiled_predictions as stp, synth
+    seg = models.UNetXceptionPatchSegmentor(320, synth.pack_weights(weights), [64, 128, 256, 512], ds_ratio=0.625,
+                                            max_patches=96)
+    small = morph.lanczos4_resize_u16(images[0], (320, 320))
+    x = morph.rescale_intensity(small, (0, 1)).astype(np.float32)
+    p1 = seg.predict(x, auto_resample=False)
+    p2 = stp.predict_img_with_smooth_windowing(x, 320, 2, seg.model.predict)
+    ref = oracle_runs[0][1]["pred"]
+    assert np.array_equal(p1, ref) and np.array_equal(p2, ref)
+    y = seg.model.predict(np.zeros((2, 320, 320), np.float32))
+    assert y.shape == (2, 320, 320, 1)
+    with pytest.raises(TypeError):
+        stp.predict_img_with_smooth_windowing(x, 320, 2, lambda b, verbose=0: b)
+    seg.handle.close()

@@ -1,0 +1,236 @@
+// Batch drivers of the branching hot path (include/tmat.h): tmat_segment_batch,
+// tmat_postprocess_batch, tmat_analyze_batch(_dev).
+//
+// Reference control flow: scripts/compute_branches.py:585-594 runs analyze_img one image at a time.
+// Here a run is cut into passes of K images (K = max_patches / patches-per-image).  Per pass the GPU
+// does Lanczos4 + rescale (preproc_kernels.hip), tile extraction, the UNet over K*200 patches
+// (unet_kernels.hip) and the f64 window blend (blend_kernels.hip) on the handle's stream; the
+// probability maps come back through pinned memory, and host worker threads run the sequential
+// graph stages (postproc.cpp, dmt.cpp, morse.cpp), one image per thread, WHILE the GPU already
+// works on the next pass.  Nothing is shared between images, so this is also how the path shards
+// across GPUs (one process per GPU, see tmat_amd/distributed.py).
+#include "../../include/tmat.h"
+#include "tmat_ctx.h"
+#include "postproc.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace tmat {
+
+void launch_lanczos(const uint16_t *img, int n, int H, int W, int h, int w, const int *xi, const float *xc, const int *yi,
+                    const float *yc, float *tmp, uint16_t *out, hipStream_t s);
+void launch_rescale01(const uint16_t *x, int n, size_t per, int *mn, int *mx, float *out, hipStream_t s);
+
+static int round_half_even(double v) { return (int)std::nearbyint(v); }
+
+// device / pinned buffers for one image geometry, cached on the handle
+static int ensure_pass_buffers(Ctx *c, int K, int H, int W, int h, int w)
+{
+    PassBuf &b = c->pass;
+    if (b.K >= K && b.H == H && b.W == W && b.h == h && b.w == w) return TMAT_OK;
+    c->free_pass();
+    std::vector<int> xi, yi;
+    std::vector<float> xc, yc;
+    lanczos_axis(W, w, xi, xc);
+    lanczos_axis(H, h, yi, yc);
+    TMAT_HIP(hipMalloc((void **)&b.xi, xi.size() * 4)); TMAT_HIP(hipMalloc((void **)&b.xc, xc.size() * 4));
+    TMAT_HIP(hipMalloc((void **)&b.yi, yi.size() * 4)); TMAT_HIP(hipMalloc((void **)&b.yc, yc.size() * 4));
+    TMAT_HIP(hipMemcpy(b.xi, xi.data(), xi.size() * 4, hipMemcpyHostToDevice));
+    TMAT_HIP(hipMemcpy(b.xc, xc.data(), xc.size() * 4, hipMemcpyHostToDevice));
+    TMAT_HIP(hipMemcpy(b.yi, yi.data(), yi.size() * 4, hipMemcpyHostToDevice));
+    TMAT_HIP(hipMemcpy(b.yc, yc.data(), yc.size() * 4, hipMemcpyHostToDevice));
+    TMAT_HIP(hipMalloc((void **)&b.tmp, (size_t)K * H * w * sizeof(float)));
+    TMAT_HIP(hipMalloc((void **)&b.small, (size_t)K * h * w * sizeof(uint16_t)));
+    TMAT_HIP(hipMalloc((void **)&b.x, (size_t)K * h * w * sizeof(float)));
+    TMAT_HIP(hipMalloc((void **)&b.mn, (size_t)K * sizeof(int))); TMAT_HIP(hipMalloc((void **)&b.mx, (size_t)K * sizeof(int)));
+    for (int i = 0; i < 2; i++) {
+        TMAT_HIP(hipMalloc((void **)&b.pred[i], (size_t)K * h * w * sizeof(double)));
+        TMAT_HIP(hipHostMalloc((void **)&b.pred_host[i], (size_t)K * h * w * sizeof(double), hipHostMallocDefault));
+        TMAT_HIP(hipEventCreateWithFlags(&b.done[i], hipEventDisableTiming));
+    }
+    b.K = K; b.H = H; b.W = W; b.h = h; b.w = w;
+    return TMAT_OK;
+}
+
+// GPU part of one pass: imgs_dev (k, H, W) u16 -> pred (k, h, w) f64 in b.pred[slot], copied to pinned host
+static int enqueue_segment(Ctx *c, const uint16_t *imgs_dev, int k, int slot)
+{
+    PassBuf &b = c->pass;
+    launch_lanczos(imgs_dev, k, b.H, b.W, b.h, b.w, b.xi, b.xc, b.yi, b.yc, b.tmp, b.small, c->stream);
+    launch_rescale01(b.small, k, (size_t)b.h * b.w, b.mn, b.mx, b.x, c->stream);
+    int rc = predict_smooth_dev(c, b.x, k, b.h, b.w, b.pred[slot]);
+    if (rc) return rc;
+    TMAT_HIP(hipMemcpyAsync(b.pred_host[slot], b.pred[slot], (size_t)k * b.h * b.w * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TMAT_HIP(hipEventRecord(b.done[slot], c->stream));
+    return TMAT_OK;
+}
+
+struct GraphParams {
+    int fh, fw;
+    float t1, t2;
+    int smooth, min_len, max_len, remove_isolated;
+};
+
+// host part for one image: pred (h, w) f64 -> row
+static int analyze_host_image(const double *pred, int h, int w, const GraphParams &gp, tmat_row *row)
+{
+    const size_t nf = (size_t)gp.fh * gp.fw;
+    std::vector<float> field(nf), f255(nf);
+    postprocess_image(pred, h, w, gp.fh, gp.fw, field.data());
+    rescale255_f32(field.data(), nf, f255.data());
+    const int cap_v = (int)nf + 4, cap_e = 3 * (int)nf + 4;
+    std::vector<int32_t> V((size_t)cap_v * 2), E((size_t)cap_e * 2);
+    int nv = 0, ne = 0;
+    int rc = dmt_graph_host(f255.data(), gp.fh, gp.fw, gp.t1, gp.t2, V.data(), cap_v, E.data(), cap_e, &nv, &ne);
+    if (rc) return rc;
+    return tmat_morse_stats(V.data(), nv, E.data(), ne, gp.fh, gp.fw, gp.smooth, gp.min_len, gp.max_len, gp.remove_isolated,
+                            nullptr, &row->count, &row->total_px, &row->avg_px, nullptr, 0);
+}
+
+struct HostJob {
+    std::vector<std::thread> threads;
+    std::atomic<int> next{0};
+    std::atomic<int> rc{0};
+    std::string err;
+    void join() { for (auto &t : threads) t.join(); threads.clear(); }
+};
+
+static int n_workers(int k)
+{
+    int hw = (int)std::thread::hardware_concurrency();
+    if (hw <= 0) hw = 4;
+    const char *e = getenv("TMAT_HOST_THREADS");
+    if (e && atoi(e) > 0) hw = atoi(e);
+    return std::max(1, std::min(hw, k));
+}
+
+static void start_host_job(HostJob &job, const double *pred_host, int k, int h, int w, const GraphParams gp, tmat_row *rows)
+{
+    job.next = 0;
+    const int nt = n_workers(k);
+    for (int t = 0; t < nt; t++)
+        job.threads.emplace_back([&job, pred_host, k, h, w, gp, rows]() {
+            for (;;) {
+                const int i = job.next.fetch_add(1);
+                if (i >= k) break;
+                int rc = analyze_host_image(pred_host + (size_t)i * h * w, h, w, gp, &rows[i]);
+                if (rc) job.rc = rc;
+            }
+        });
+}
+
+static int analyze_dev(Ctx *c, const uint16_t *imgs_dev, int n, int H, int W, double ds_ratio, int ds_width, GraphParams gp,
+                       int64_t first_index, tmat_row *rows)
+{
+    const int h = round_half_even((double)H * ds_ratio), w = round_half_even((double)W * ds_ratio);
+    if (h < 1 || w < 1) { set_error("analyze: target shape is empty"); return TMAT_E_ARG; }
+    gp.fh = round_half_even((double)H * ((double)ds_width / (double)W));
+    gp.fw = round_half_even((double)W * ((double)ds_width / (double)W));
+    TileGeom g = make_geom(h, w, c->patch);
+    if (g.tiles_per_img > c->max_patches) { set_error("analyze: image needs more patches than max_patches"); return TMAT_E_ARG; }
+    const int K = std::min(n, c->max_patches / g.tiles_per_img);
+    int rc = ensure_pass_buffers(c, K, H, W, h, w);
+    if (rc) return rc;
+    for (int i = 0; i < n; i++) { rows[i].index = first_index + i; rows[i].count = 0; rows[i].total_px = 0; rows[i].avg_px = 0; }
+    const int P = (n + K - 1) / K;
+    HostJob jobs[2];
+    auto cnt = [&](int p) { return std::min(K, n - p * K); };
+    rc = enqueue_segment(c, imgs_dev, cnt(0), 0);
+    for (int p = 0; p < P && !rc; p++) {
+        const int slot = p & 1;
+        if (!hip_ok(hipEventSynchronize(c->pass.done[slot]), "hipEventSynchronize")) { rc = TMAT_E_HIP; break; }
+        if (p >= 1) { jobs[slot ^ 1].join(); if (jobs[slot ^ 1].rc) rc = jobs[slot ^ 1].rc; }
+        if (p + 1 < P && !rc) rc = enqueue_segment(c, imgs_dev + (size_t)(p + 1) * K * H * W, cnt(p + 1), slot ^ 1);
+        if (!rc) start_host_job(jobs[slot], c->pass.pred_host[slot], cnt(p), h, w, gp, rows + (size_t)p * K);
+    }
+    for (auto &j : jobs) { j.join(); if (j.rc && !rc) rc = j.rc; }
+    hipStreamSynchronize(c->stream);
+    return rc;
+}
+
+}  // namespace tmat
+
+using namespace tmat;
+
+extern "C" {
+
+int tmat_segment_batch(tmat_handle hd, const uint16_t *imgs, int n, int H, int W, double ds_ratio, double *pred)
+{
+    Ctx *c = (Ctx *)hd;
+    if (!c || !imgs || !pred || n < 0 || H < 1 || W < 1) { set_error("tmat_segment_batch: bad argument"); return TMAT_E_ARG; }
+    if (n == 0) return TMAT_OK;
+    TMAT_HIP(hipSetDevice(c->device));
+    const int h = round_half_even((double)H * ds_ratio), w = round_half_even((double)W * ds_ratio);
+    if (h < 1 || w < 1) { set_error("tmat_segment_batch: target shape is empty"); return TMAT_E_ARG; }
+    TileGeom g = make_geom(h, w, c->patch);
+    if (g.tiles_per_img > c->max_patches) { set_error("tmat_segment_batch: image needs more patches than max_patches"); return TMAT_E_ARG; }
+    const int K = std::min(n, c->max_patches / g.tiles_per_img);
+    int rc = ensure_pass_buffers(c, K, H, W, h, w);
+    if (rc) return rc;
+    uint16_t *dimg = nullptr;
+    TMAT_HIP(hipMalloc((void **)&dimg, (size_t)K * H * W * sizeof(uint16_t)));
+    for (int i0 = 0; i0 < n && !rc; i0 += K) {
+        const int k = std::min(K, n - i0);
+        if (!hip_ok(hipMemcpyAsync(dimg, imgs + (size_t)i0 * H * W, (size_t)k * H * W * 2, hipMemcpyHostToDevice, c->stream), "H2D")) { rc = TMAT_E_HIP; break; }
+        rc = enqueue_segment(c, dimg, k, 0);
+        if (rc) break;
+        if (!hip_ok(hipStreamSynchronize(c->stream), "sync")) { rc = TMAT_E_HIP; break; }
+        std::memcpy(pred + (size_t)i0 * h * w, c->pass.pred_host[0], (size_t)k * h * w * sizeof(double));
+    }
+    hipFree(dimg);
+    return rc;
+}
+
+int tmat_postprocess_batch(tmat_handle, const double *pred, int n, int hh, int ww, int out_h, int out_w, float *field)
+{
+    if (!pred || !field || n < 0 || hh < 1 || ww < 1 || out_h < 1 || out_w < 1) { set_error("tmat_postprocess_batch: bad argument"); return TMAT_E_ARG; }
+    std::atomic<int> next{0};
+    std::vector<std::thread> th;
+    const int nt = n_workers(n);
+    for (int t = 0; t < nt; t++)
+        th.emplace_back([&]() {
+            for (;;) {
+                const int i = next.fetch_add(1);
+                if (i >= n) break;
+                postprocess_image(pred + (size_t)i * hh * ww, hh, ww, out_h, out_w, field + (size_t)i * out_h * out_w);
+            }
+        });
+    for (auto &t : th) t.join();
+    return TMAT_OK;
+}
+
+int tmat_analyze_batch_dev(tmat_handle hd, const uint16_t *imgs_dev, int n, int H, int W, double ds_ratio, int ds_width,
+                           float graph_thresh_1, float graph_thresh_2, int smoothing_window_px, int min_branch_length_px,
+                           int max_branch_length_px, int remove_isolated, int64_t first_index, tmat_row *rows)
+{
+    Ctx *c = (Ctx *)hd;
+    if (!c || !imgs_dev || !rows || n < 0 || H < 1 || W < 1 || ds_width < 1) { set_error("tmat_analyze_batch_dev: bad argument"); return TMAT_E_ARG; }
+    if (n == 0) return TMAT_OK;
+    TMAT_HIP(hipSetDevice(c->device));
+    GraphParams gp{0, 0, graph_thresh_1, graph_thresh_2, smoothing_window_px, min_branch_length_px, max_branch_length_px, remove_isolated};
+    return analyze_dev(c, imgs_dev, n, H, W, ds_ratio, ds_width, gp, first_index, rows);
+}
+
+int tmat_analyze_batch(tmat_handle hd, const uint16_t *imgs, int n, int H, int W, double ds_ratio, int ds_width,
+                       float graph_thresh_1, float graph_thresh_2, int smoothing_window_px, int min_branch_length_px,
+                       int max_branch_length_px, int remove_isolated, int64_t first_index, tmat_row *rows)
+{
+    Ctx *c = (Ctx *)hd;
+    if (!c || !imgs || !rows || n < 0) { set_error("tmat_analyze_batch: bad argument"); return TMAT_E_ARG; }
+    if (n == 0) return TMAT_OK;
+    TMAT_HIP(hipSetDevice(c->device));
+    uint16_t *dimg = nullptr;
+    TMAT_HIP(hipMalloc((void **)&dimg, (size_t)n * H * W * sizeof(uint16_t)));
+    int rc = TMAT_OK;
+    if (!hip_ok(hipMemcpy(dimg, imgs, (size_t)n * H * W * 2, hipMemcpyHostToDevice), "H2D")) rc = TMAT_E_HIP;
+    if (!rc) rc = tmat_analyze_batch_dev(hd, dimg, n, H, W, ds_ratio, ds_width, graph_thresh_1, graph_thresh_2, smoothing_window_px,
+                                         min_branch_length_px, max_branch_length_px, remove_isolated, first_index, rows);
+    hipFree(dimg);
+    return rc;
+}
+
+}  // extern "C"

@@ -52,7 +52,7 @@ static void lanczos4_coeffs(float x, float *co)
     for (int i = 0; i < 8; i++) co[i] = co[i] * inv;
 }
 
-static void lanczos_axis(int n_src, int n_dst, std::vector<int> &idx, std::vector<float> &co)
+void lanczos_axis(int n_src, int n_dst, std::vector<int> &idx, std::vector<float> &co)
 {
     idx.resize((size_t)n_dst * 8); co.resize((size_t)n_dst * 8);
     const double scale = 1.0 / ((double)n_dst / (double)n_src);

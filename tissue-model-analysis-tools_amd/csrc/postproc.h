@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <vector>
 namespace tmat {
+void lanczos_axis(int n_src, int n_dst, std::vector<int> &idx, std::vector<float> &co);
 void lanczos4_resize_u16(const uint16_t *img, int H, int W, int h, int w, uint16_t *out);
 void rescale01_u16(const uint16_t *img, size_t n, float *out);
 void rescale255_f32(const float *img, size_t n, float *out);

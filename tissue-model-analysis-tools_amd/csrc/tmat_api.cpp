@@ -343,6 +343,7 @@ void tmat_destroy(tmat_handle h)
     if (c->patch_out) hipFree(c->patch_out);
     if (c->scratch) hipFree(c->scratch);
     if (c->win1d) hipFree(c->win1d);
+    c->free_pass();
     for (auto &e : c->ev_open) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);

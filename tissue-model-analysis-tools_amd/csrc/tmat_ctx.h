@@ -21,6 +21,19 @@ struct UpBlock {
 };
 struct ProfEv { hipEvent_t e0, e1; double flops; };
 
+// per-geometry buffers of the batch pipeline (pipeline.cpp)
+struct PassBuf {
+    int K = 0, H = 0, W = 0, h = 0, w = 0;
+    int *xi = nullptr, *yi = nullptr;
+    float *xc = nullptr, *yc = nullptr;
+    float *tmp = nullptr, *x = nullptr;
+    uint16_t *small = nullptr;
+    int *mn = nullptr, *mx = nullptr;
+    double *pred[2] = {nullptr, nullptr};
+    double *pred_host[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+};
+
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -38,6 +51,18 @@ struct Ctx {
     size_t scratch_bytes = 0;
     double *win1d = nullptr;
     std::vector<double> win_host;
+    PassBuf pass;
+    void free_pass()
+    {
+        PassBuf &b = pass;
+        void *dev[] = {b.xi, b.yi, b.xc, b.yc, b.tmp, b.x, b.small, b.mn, b.mx, b.pred[0], b.pred[1]};
+        for (void *p : dev) if (p) hipFree(p);
+        for (int i = 0; i < 2; i++) {
+            if (b.pred_host[i]) hipHostFree(b.pred_host[i]);
+            if (b.done[i]) hipEventDestroy(b.done[i]);
+        }
+        pass = PassBuf();
+    }
     // profiling of the dominant kernel family
     bool prof_on = false;
     std::vector<ProfEv> ev_open;

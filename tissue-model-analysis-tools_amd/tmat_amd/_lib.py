@@ -44,13 +44,13 @@ def lib():
     L.tmat_sync.argtypes = [vp]
     L.tmat_unet_predict.argtypes = [vp, vp, i, vp]
     L.tmat_predict_smooth.argtypes = [vp, vp, i, i, i, vp]
-    L.tmat_segment_batch.argtypes = [vp, vp, i, i, i, f, vp]
-    L.tmat_postprocess_batch.argtypes = [vp, vp, i, i, i, i, vp]
+    L.tmat_segment_batch.argtypes = [vp, vp, i, i, i, C.c_double, vp]
+    L.tmat_postprocess_batch.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.tmat_dmt_graph.argtypes = [vp, vp, i, i, f, f, vp, i, vp, i, C.POINTER(i), C.POINTER(i)]
     L.tmat_morse_stats.argtypes = [vp, i, vp, i, i, i, i, i, i, i, vp, C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                    C.POINTER(C.c_double), vp, i]
-    L.tmat_analyze_batch_dev.argtypes = [vp, vp, i, i, i, f, i, f, f, i, i, i, i, C.c_int64, vp]
-    L.tmat_analyze_batch.argtypes = [vp, vp, i, i, i, f, i, f, f, i, i, i, i, C.c_int64, vp]
+    L.tmat_analyze_batch_dev.argtypes = [vp, vp, i, i, i, C.c_double, i, f, f, i, i, i, i, C.c_int64, vp]
+    L.tmat_analyze_batch.argtypes = [vp, vp, i, i, i, C.c_double, i, f, f, i, i, i, i, C.c_int64, vp]
     L.tmat_dev_alloc.argtypes = [vp, sz, C.POINTER(vp)]
     L.tmat_dev_free.argtypes = [vp, vp]
     L.tmat_dev_upload.argtypes = [vp, vp, vp, sz]
@@ -68,7 +68,9 @@ EXPORTS = [
     "tmat_last_error", "tmat_version", "tmat_create", "tmat_destroy", "tmat_sync", "tmat_unet_predict",
     "tmat_predict_smooth", "tmat_segment_batch", "tmat_postprocess_batch", "tmat_dmt_graph", "tmat_morse_stats",
     "tmat_analyze_batch_dev", "tmat_analyze_batch", "tmat_dev_alloc", "tmat_dev_free", "tmat_dev_upload",
-    "tmat_prof_enable", "tmat_prof_read",
+    "tmat_prof_enable", "tmat_prof_read", "tmat_host_lanczos4_u16", "tmat_host_rescale01_u16",
+    "tmat_host_rescale255_f32", "tmat_host_filter_mask", "tmat_host_skeletonize", "tmat_host_medial_axis",
+    "tmat_host_permutation", "tmat_host_postprocess",
 ]
 
 

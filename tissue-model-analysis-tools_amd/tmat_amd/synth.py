@@ -30,13 +30,14 @@ MAGIC = b"TMATW001"
 # --------------------------------------------------------------------------------------
 # images
 # --------------------------------------------------------------------------------------
-def synth_image(index: int, size: int = 1024, n_vessels: int = 40) -> np.ndarray:
-    """uint16 (size, size) synthetic Z-projection, deterministic in `index`."""
+def synth_image(index: int, size: int = 1024, n_vessels: int = 40, scale: float = None) -> np.ndarray:
+    """uint16 (size, size) synthetic Z-projection, deterministic in `index`.  Vessel widths and blur
+    scale with size/1024 unless `scale` is given (scale=1: a crop-like image at full resolution)."""
     from scipy.ndimage import gaussian_filter
 
     rs = np.random.RandomState(1234 + index)
     img = 2000.0 + rs.normal(0.0, 500.0, (size, size))
-    scale = size / 1024.0
+    scale = size / 1024.0 if scale is None else float(scale)
     tt = np.linspace(0.0, 1.0, int(700 * scale) + 50)[:, None]
     b0, b1, b2, b3 = (1 - tt) ** 3, 3 * (1 - tt) ** 2 * tt, 3 * (1 - tt) * tt**2, tt**3
     for _ in range(n_vessels):
@@ -93,8 +94,16 @@ def layer_plan(filter_counts=FILTER_COUNTS):
     return plan
 
 
-def synth_weights(seed: int = 0, filter_counts=FILTER_COUNTS, noise: float = 1e-3,
-                  out_gain: float = 30.0, out_bias: float = -4.5) -> "OrderedDict[str, np.ndarray]":
+def synth_weights(seed: int = 0, filter_counts=FILTER_COUNTS, noise: float = 1e-3, sat_thresh: float = 0.25,
+                  sat_gain: float = 6.0, out_gain: float = 12.0, out_bias: float = -8.0) -> "OrderedDict[str, np.ndarray]":
+    """Random-init weights of the reference architecture with a hand-built channel-0 signal path:
+    stem 3x3 box -> soft binarisation min(max(g (a - t), 0), 1) (two ReLU stages of down block 0) ->
+    three max-pools (keeps thin vessels connected down to the 20x20 bottleneck) -> [1 2 1]^2/16
+    smoothing in every transposed conv of the up path -> final conv gain/bias -> sigmoid.
+    All other weights are N(0, noise): every MAC of the architecture is live.  The decoder of this
+    architecture (nearest upsampling + translation-invariant convs) cannot be hand-wired to emit
+    detail finer than the 16-px bottleneck grid, so the synthetic masks are coarser than a trained
+    model's; see DESIGN.md "Synthetic workload"."""
     rs = np.random.RandomState(seed)
     w = OrderedDict()
     for name, shape in layer_plan(filter_counts):
@@ -104,24 +113,34 @@ def synth_weights(seed: int = 0, filter_counts=FILTER_COUNTS, noise: float = 1e-
             bn[1] = rs.normal(0, noise, shape[1])        # beta
             bn[2] = rs.normal(0, noise, shape[1])        # moving mean
             bn[3] = 1.0 + rs.uniform(0, 0.02, shape[1])  # moving variance
+            bn[:, 0] = (1.0, 0.0, 0.0, 1.0 - BN_EPS)     # channel 0: identity
             w[name] = bn.astype(np.float32)
         else:
             w[name] = rs.normal(0, noise, shape).astype(np.float32)
     smooth = np.outer([1, 2, 1], [1, 2, 1]).astype(np.float32) / 16.0
-    # channel-0 signal path
     w["stem.w"][:, :, 0, 0] = 1.0 / 9.0
+    w["stem.b"][0] = 0.0
     for i in range(len(filter_counts) - 1):
         p = f"down{i}"
         for s in ("sep1", "sep2"):
             w[f"{p}.{s}.dw"][:, :, 0] = 0.0
             w[f"{p}.{s}.dw"][1, 1, 0] = 1.0
             w[f"{p}.{s}.pw"][0, 0] = 1.0
+            w[f"{p}.{s}.b"][0] = 0.0
         w[f"{p}.res.w"][0, 0] = 0.0
+        w[f"{p}.res.b"][0] = 0.0
+    # soft binarisation in down block 0: u = relu(1 - g (a - t)); v = 1 - u
+    w["down0.sep1.pw"][0, 0] = -sat_gain
+    w["down0.sep1.b"][0] = 1.0 + sat_gain * sat_thresh
+    w["down0.sep2.pw"][0, 0] = -1.0
+    w["down0.sep2.b"][0] = 1.0
     for j in range(len(filter_counts)):
         p = f"up{j}"
         for s in ("ct1", "ct2"):
             w[f"{p}.{s}.w"][:, :, 0, 0] = smooth
+            w[f"{p}.{s}.b"][0] = 0.0
         w[f"{p}.res.w"][0, 0] = 0.0
+        w[f"{p}.res.b"][0] = 0.0
     w["final.w"][:, :, 0] = out_gain * smooth
     w["final.b"][0] = out_bias
     return w
