@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Analyze microvessels in a directory of 2-D Z-projections -- MI355X drop-in for the reference's
+scripts/compute_branches.py (2-D branch): same positional arguments, flags, config keys, CSV
+(utf-16, same header), config.json and exit behaviour (message + exit code 1).
+
+    python compute_branches.py IN_ROOT OUT_ROOT [--image-width-microns F] [--graph-thresh-1 F ...]
+        [--graph-thresh-2 F ...] [--min-branch-length F] [--max-branch-length F]
+        [--remove-isolated-branches] [--graph-smoothing-window F] [-c CONFIG] [--channel N] [--time N] [-w]
+
+Differences (documented in INTEGRATION.md): images are analysed in batches on the GPU (one process
+per GPU under torch.distributed.run; rows are gathered over RCCL and rank 0 writes the CSV);
+Z-stack inputs, --detect-well and the PNG visualisations are outside the accelerated path;
+--image-width-microns (or the config key) is required because image metadata is not parsed.
+"""
+import argparse
+import csv
+import json
+import os
+import sys
+from glob import glob
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parents[1]
+if str(PKG) not in sys.path:
+    sys.path.insert(0, str(PKG))
+
+import numpy as np  # noqa: E402
+
+DEFAULT_CONFIG_PATH = str(PKG / "config" / "default_branching_computation.json")
+DOWNSAMPLE_WIDTH = 384
+FAIL = "\033[91m[FAILURE]\033[0m"
+OK = "\033[92m[SUCCESS]\033[0m"
+
+
+def parse_branching_args(arg_defaults):
+    """same surface as the reference's script_util.parse_branching_args (script_util.py:40-204)"""
+    p = argparse.ArgumentParser()
+    p.add_argument("in_root", type=str)
+    p.add_argument("out_root", type=str)
+    p.add_argument("--channel", type=int, default=None)
+    p.add_argument("--time", type=int, default=None)
+    p.add_argument("-w", "--detect-well", action="store_true")
+    p.add_argument("--image-width-microns", type=float, default=None)
+    p.add_argument("--graph-thresh-1", nargs="+", type=float, default=None)
+    p.add_argument("--graph-thresh-2", nargs="+", type=float, default=None)
+    p.add_argument("--min-branch-length", type=float, default=None)
+    p.add_argument("--max-branch-length", type=float, default=None)
+    p.add_argument("--remove-isolated-branches", action="store_true")
+    p.add_argument("--graph-smoothing-window", type=float, default=None)
+    p.add_argument("-c", "--config", type=str, default=arg_defaults["default_config_path"])
+    args = p.parse_args()
+    if not args.remove_isolated_branches:
+        args.remove_isolated_branches = None
+    for k, v in vars(args).items():
+        if isinstance(v, str):
+            setattr(args, k, v.strip("'\""))
+    return args
+
+
+def get_unique_output_filepath(file):
+    file = Path(file)
+    name, ext = os.path.splitext(file.name)
+    n = 1
+    while file.exists():
+        n += 1
+        file = file.parent / f"{name}-{n}{ext}"
+    return file
+
+
+def create_output_csv(output_file: Path):
+    fields = ["Image", "Total # of branches", "Total branch length (µm)", "Average branch length (µm)"]
+    with open(output_file, "w", encoding="utf-16") as f:
+        csv.writer(f, lineterminator="\n").writerow(fields)
+
+
+def load_image_2d(path: str, channel=None, time=None) -> np.ndarray:
+    if path.endswith(".npy"):
+        a = np.load(path)
+    else:
+        from PIL import Image
+        a = np.array(Image.open(path))
+    if a.ndim == 3 and channel is not None:
+        a = a[..., channel] if a.shape[-1] <= 4 else a[channel]
+    if a.ndim != 2:
+        raise ValueError(f"{path}: expected a single-channel 2-D image, got shape {a.shape}")
+    if a.dtype == np.uint8:
+        a = a.astype(np.uint16)
+    if a.dtype != np.uint16:
+        raise ValueError(f"{path}: expected uint8/uint16 pixels, got {a.dtype}")
+    return a
+
+
+def main(args=None):
+    if args is None:
+        args = parse_branching_args({"default_config_path": DEFAULT_CONFIG_PATH})
+        if not Path(args.config).is_file():
+            print(f"{FAIL} Config file {args.config} does not exist.", flush=True)
+            sys.exit(1)
+        with open(args.config, "r", encoding="utf8") as fp:
+            config = json.load(fp)
+    else:
+        config = {}
+    ad = vars(args)
+    for prm in ("image_width_microns", "graph_thresh_1", "graph_thresh_2", "graph_smoothing_window", "min_branch_length",
+                "max_branch_length", "remove_isolated_branches"):
+        if prm not in config or ad.get(prm) is not None:
+            config[prm] = ad.get(prm)
+    model_cfg_path = config.get("model_cfg_path")
+    if not model_cfg_path:
+        cfgs = sorted(glob(str(PKG / "model_training" / "binary_segmentation" / "configs" / "unet_patch_segmentor_*.json")),
+                      key=lambda s: int(Path(s).stem.rsplit("_", 1)[1]))
+        model_cfg_path = cfgs[-1] if cfgs else ""
+    if not Path(model_cfg_path).is_file():
+        print(f"{FAIL}Model config file {model_cfg_path} does not exist.", flush=True)
+        sys.exit(1)
+    if getattr(args, "detect_well", False):
+        print(f"{FAIL} --detect-well is not available in the accelerated path (unseeded random search in the reference).", flush=True)
+        sys.exit(1)
+    in_root, out_root = Path(args.in_root), Path(args.out_root)
+    if not in_root.is_dir():
+        print(f"{FAIL} Input directory {in_root} does not exist.", flush=True)
+        sys.exit(1)
+    try:
+        out_root.mkdir(parents=True, exist_ok=True)
+    except PermissionError as e:
+        print(f"{FAIL} {e}", flush=True)
+        sys.exit(1)
+    paths = {Path(fp).stem: fp for fp in glob(str(in_root / "*")) if os.path.isfile(fp)}
+    if not paths:
+        print(f"{FAIL}No images found in {in_root}", flush=True)
+        sys.exit(1)
+    if config.get("image_width_microns") is None:
+        print(f"{FAIL} The --image-width-microns parameter was not specified (image metadata is not parsed by the "
+              "accelerated path). Specify it and try again. Exiting...", flush=True)
+        sys.exit(1)
+
+    from tmat_amd import branches, distributed, models
+    ws, rank, local_rank = distributed.world()
+    if ws > 1:
+        import torch
+        import torch.distributed as dist
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend)
+    model = models.get_unet_patch_segmentor_from_cfg(model_cfg_path, device_id=local_rank)
+
+    ids = sorted(paths)
+    mine = [ids[i] for i in distributed.shard_indices(len(ids), rank, ws)]
+    grid = branches.threshold_grid(config)
+    results = {suffix: [] for _, suffix in grid}
+    # batch images of equal shape
+    by_shape = {}
+    for gi, img_id in enumerate(mine):
+        print(f"Analyzing {img_id}...", flush=True)
+        img = load_image_2d(paths[img_id], args.channel, args.time)
+        by_shape.setdefault(img.shape, []).append((ids.index(img_id), img))
+    for shape, items in by_shape.items():
+        batch = np.stack([im for _, im in items])
+        for cfg, suffix in grid:
+            rows = branches.analyze_batch(model.handle, batch, config, config["image_width_microns"], model.ds_ratio,
+                                          thresh=(cfg["thresh1"], cfg["thresh2"]))
+            for (gidx, _), r in zip(items, rows):
+                results[suffix].append((gidx, r[1], r[2], r[3]))
+    created = set()
+    for _, suffix in grid:
+        rows = distributed.gather_rows(results[suffix])
+        if rank != 0:
+            continue
+        output_file = out_root / f"branching_analysis{suffix}.csv"
+        n = 1
+        while output_file.is_file() and str(output_file) not in created:
+            n += 1
+            output_file = out_root / f"branching_analysis{suffix}-{n}.csv"
+        create_output_csv(output_file)
+        created.add(str(output_file))
+        with open(output_file, "a", encoding="utf-16") as f:
+            wr = csv.writer(f, lineterminator="\n")
+            for gidx, cnt, tot_px, avg_px in rows:
+                um = lambda px: branches.pixels_to_microns(px, DOWNSAMPLE_WIDTH, config["image_width_microns"])
+                wr.writerow([ids[gidx], cnt, um(tot_px), um(avg_px)])
+        print(f"Results saved to {output_file}.", flush=True)
+    if rank == 0:
+        config["time"], config["channel"] = getattr(args, "time", None), getattr(args, "channel", None)
+        with open(get_unique_output_filepath(out_root / "config.json"), "w", encoding="utf8") as f:
+            json.dump({k: v for k, v in config.items() if v is not None}, f, indent=4)
+        print(f"{OK} Analysis complete.", flush=True)
+    model.handle.close()
+    if ws > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
