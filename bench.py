@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    t_start = time.perf_counter()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -86,8 +87,14 @@ def main():
     def handle_sync():
         _lib.check(L.tmat_sync(handle.raw), "sync")
 
+    def log(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    log(f"inputs resident in HBM ({n_img} images/GPU), starting {args.warmup} warmup step(s)")
     for _ in range(args.warmup):
         rows = step()
+    log("warmup done, timing")
     handle.prof_enable(True)
     handle.prof_read(True)
     barrier()
@@ -96,6 +103,7 @@ def main():
         rows = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    log(f"timed region {elapsed:.2f} s")
     conv_ms, conv_launches, conv_flops = handle.prof_read(True)
     handle.prof_enable(False)
 
@@ -137,6 +145,7 @@ def main():
         # reference CPU path = the oracle port with all-core PyTorch-CPU convolutions, on a bounded sample
         from oracle import pipeline
         torch.set_num_threads(os.cpu_count() or 8)
+        log("timing the CPU baseline (oracle port, PyTorch-CPU UNet) on one image")
         t0 = time.perf_counter()
         n0, tot0, avg0 = pipeline.analyze_image(host[0], weights, CFG, IMAGE_WIDTH_MICRONS, unet_kind="torch")
         dt = time.perf_counter() - t0

@@ -17,6 +17,8 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <chrono>
+#include <cstdio>
 #include <thread>
 
 namespace tmat {
@@ -76,19 +78,29 @@ struct GraphParams {
 };
 
 // host part for one image: pred (h, w) f64 -> row
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static bool trace_on() { static int t = -1; if (t < 0) { const char *e = getenv("TMAT_TRACE"); t = e && atoi(e) > 0; } return t; }
+
 static int analyze_host_image(const double *pred, int h, int w, const GraphParams &gp, tmat_row *row)
 {
     const size_t nf = (size_t)gp.fh * gp.fw;
     std::vector<float> field(nf), f255(nf);
+    const double t0 = now_s();
     postprocess_image(pred, h, w, gp.fh, gp.fw, field.data());
+    const double t1 = now_s();
     rescale255_f32(field.data(), nf, f255.data());
     const int cap_v = (int)nf + 4, cap_e = 3 * (int)nf + 4;
     std::vector<int32_t> V((size_t)cap_v * 2), E((size_t)cap_e * 2);
     int nv = 0, ne = 0;
     int rc = dmt_graph_host(f255.data(), gp.fh, gp.fw, gp.t1, gp.t2, V.data(), cap_v, E.data(), cap_e, &nv, &ne);
     if (rc) return rc;
-    return tmat_morse_stats(V.data(), nv, E.data(), ne, gp.fh, gp.fw, gp.smooth, gp.min_len, gp.max_len, gp.remove_isolated,
-                            nullptr, &row->count, &row->total_px, &row->avg_px, nullptr, 0);
+    const double t2 = now_s();
+    rc = tmat_morse_stats(V.data(), nv, E.data(), ne, gp.fh, gp.fw, gp.smooth, gp.min_len, gp.max_len, gp.remove_isolated,
+                          nullptr, &row->count, &row->total_px, &row->avg_px, nullptr, 0);
+    if (trace_on())
+        fprintf(stderr, "[tmat] host image %lld: postprocess %.1f ms, dmt %.1f ms (%d verts), morse %.1f ms -> %lld branches\n",
+                (long long)row->index, (t1 - t0) * 1e3, (t2 - t1) * 1e3, nv, (now_s() - t2) * 1e3, (long long)row->count);
+    return rc;
 }
 
 struct HostJob {
@@ -142,8 +154,13 @@ static int analyze_dev(Ctx *c, const uint16_t *imgs_dev, int n, int H, int W, do
     rc = enqueue_segment(c, imgs_dev, cnt(0), 0);
     for (int p = 0; p < P && !rc; p++) {
         const int slot = p & 1;
+        const double tw0 = now_s();
         if (!hip_ok(hipEventSynchronize(c->pass.done[slot]), "hipEventSynchronize")) { rc = TMAT_E_HIP; break; }
+        const double tw1 = now_s();
         if (p >= 1) { jobs[slot ^ 1].join(); if (jobs[slot ^ 1].rc) rc = jobs[slot ^ 1].rc; }
+        if (trace_on())
+            fprintf(stderr, "[tmat] pass %d/%d (%d images): waited %.1f ms for the GPU, %.1f ms for host jobs of the previous pass\n",
+                    p + 1, P, cnt(p), (tw1 - tw0) * 1e3, (now_s() - tw1) * 1e3);
         if (p + 1 < P && !rc) rc = enqueue_segment(c, imgs_dev + (size_t)(p + 1) * K * H * W, cnt(p + 1), slot ^ 1);
         if (!rc) start_host_job(jobs[slot], c->pass.pred_host[slot], cnt(p), h, w, gp, rows + (size_t)p * K);
     }
