@@ -33,6 +33,55 @@ SIZE = 1024
 MFMA_F32_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: f32-input MFMA = vector f32 peak
 
 
+def cpu_baseline(img, weights, handle, log, n_sample_patches=40):
+    """Reference CPU path = the oracle port (PyTorch-CPU convolutions on all usable cores + the oracle's
+    numpy/C host stages), timed on a BOUNDED sample of one 1024x1024 image of the workload:
+    all non-UNet stages in full, the UNet on `n_sample_patches` of the image's 200 patches (scaled up)."""
+    import torch
+    from oracle import blend, dmt, morph, morse, pipeline, unet as ou
+    from tmat_amd import _lib
+    cores = ou.usable_cores()
+    torch.set_num_threads(cores)
+    log(f"timing the CPU baseline (oracle port, PyTorch-CPU UNet, {cores} threads) on a bounded sample of one image")
+    t = time.perf_counter
+    t0 = t()
+    small = morph.lanczos4_resize_u16(img, morph.target_shape(img.shape, 0.625))
+    x = morph.rescale_intensity(small, (0, 1)).astype(np.float32)
+    t_pre = t() - t0
+    # tiles of the first D4 orientation (the same patches the reference feeds to keras predict)
+    pad = np.pad(x, 160, constant_values=x.min())
+    tiles = np.array([pad[i:i + 320, j:j + 320] for i in range(0, 641, 160) for j in range(0, 641, 160)])
+    ou.forward_torch(weights, tiles[:2])                      # warm the thread pool
+    t0 = t()
+    done = 0
+    while done < n_sample_patches:
+        k = min(16, n_sample_patches - done)                  # INFERENCE_BATCH_SIZE = 16
+        ou.forward_torch(weights, tiles[(np.arange(k) + done) % len(tiles)])
+        done += k
+        log(f"  cpu baseline: {done}/{n_sample_patches} sample patches")
+    t_unet = (t() - t0) * (200.0 / n_sample_patches)
+    t0 = t()
+    blend.predict_img_with_smooth_windowing(x, 320, 2, lambda b, verbose=0: np.asarray(b)[..., None])
+    t_blend = t() - t0
+    # downstream stages on the probability map of the same image (taken from the GPU path)
+    pred = np.empty((1,) + x.shape, np.float64)
+    _lib.check(_lib.lib().tmat_segment_batch(handle.raw, _lib.ptr(np.ascontiguousarray(img[None])), 1, img.shape[0], img.shape[1],
+                                             0.625, _lib.ptr(pred)), "segment")
+    t0 = t()
+    field, _, _ = morph.postprocess(pred[0], morph.dsamp_shape(img.shape, 384))
+    f255 = morph.rescale_intensity(field, (0, 255))
+    V, E = dmt.compute_dmt_graph(f255, 5.0, 10.0)
+    sw, mn, mx = pipeline.px_params(CFG, 384, IMAGE_WIDTH_MICRONS)
+    _, n0, tot0, _ = morse.morse_stats(V, E, field.shape, sw, mn, mx, False, None)
+    t_post = t() - t0
+    total = t_pre + t_unet + t_blend + t_post
+    log(f"  cpu baseline: pre {t_pre:.2f}s unet(scaled) {t_unet:.2f}s blend {t_blend:.2f}s post+graph {t_post:.2f}s")
+    return {"value": round(1.0 / total, 5), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"one 1024x1024 image: all non-UNet stages in full; UNet (PyTorch-CPU, as-written graph) on {n_sample_patches} of its "
+                      "200 patches, time scaled by 200/%d" % n_sample_patches,
+            "seconds_per_image": round(total, 2), "unet_seconds_per_image": round(t_unet, 2), "count": int(n0)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,7 +100,11 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    os.environ.setdefault("TMAT_HOST_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, world))))
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 8
+    os.environ.setdefault("TMAT_HOST_THREADS", str(max(1, min(ncpu // max(1, world), 32))))
 
     import torch
     dist = None
@@ -142,16 +195,7 @@ def main():
         out["config"]["sample_rows"] = [[int(r[0]), int(r[1]), round(r[2], 3)] for r in sample]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # reference CPU path = the oracle port with all-core PyTorch-CPU convolutions, on a bounded sample
-        from oracle import pipeline
-        torch.set_num_threads(os.cpu_count() or 8)
-        log("timing the CPU baseline (oracle port, PyTorch-CPU UNet) on one image")
-        t0 = time.perf_counter()
-        n0, tot0, avg0 = pipeline.analyze_image(host[0], weights, CFG, IMAGE_WIDTH_MICRONS, unet_kind="torch")
-        dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": round(1.0 / dt, 5), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": "1 of the 1024x1024 images (6.2 TFLOP of convolutions), oracle pipeline with PyTorch-CPU UNet",
-                               "count_cpu": int(n0), "count_gpu": int(rows[0][1])}
+        out["cpu_baseline"] = cpu_baseline(host[0], weights, handle, log)
     elif rank == 0:
         out["cpu_baseline"] = None
 

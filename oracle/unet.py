@@ -42,9 +42,19 @@ def build(force: bool = False) -> Path:
     return so
 
 
+def usable_cores() -> int:
+    """cores this process may really use (affinity mask, capped at 16 = one GPU's share of the box)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 8
+    return max(1, min(n, int(os.environ.get("TMAT_ORACLE_THREADS", "16"))))
+
+
 def lib():
     global _lib
     if _lib is None:
+        os.environ.setdefault("OMP_NUM_THREADS", str(usable_cores()))
         _lib = ctypes.CDLL(str(build()))
         _lib.orc_sigmoid.restype = ctypes.c_float
         _lib.orc_sigmoid.argtypes = [ctypes.c_float]

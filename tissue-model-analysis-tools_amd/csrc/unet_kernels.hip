@@ -77,41 +77,49 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int M, int H
     }
     const int brow = t / BV, bcol = (t % BV) * 4;
 
-    float4 ra[NPA], rb[NPB];
-    auto load_chunk = [&](int c) {
-        const int tap = c / cchunks;
-        const int c0 = (c - tap * cchunks) * KC;
-        const int dy = a.ksize == 3 ? tap / 3 - 1 : 0;
-        const int dx = a.ksize == 3 ? tap % 3 - 1 : 0;
-#pragma unroll
-        for (int i = 0; i < NPA; i++) {
-            int yy = py[i] + dy, xx = px[i] + dx;
-            bool ok = pok[i] && yy >= 0 && yy < H && xx >= 0 && xx < W;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                size_t off = ((size_t)(pbase[i] + (yy >> a.up)) * a.w + (xx >> a.up)) * a.Cin + c0 + c4;
-                v = *reinterpret_cast<const float4 *>(a.in + off);
-                if (a.relu_in) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
-            }
-            ra[i] = v;
-        }
-        const float *wp = a.W + ((size_t)tap * a.Cin + c0) * a.Cout + n0 + bcol;
-#pragma unroll
-        for (int i = 0; i < NPB; i++)
-            rb[i] = *reinterpret_cast<const float4 *>(wp + (size_t)(i * RPP + brow) * a.Cout);
-    };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NPA; i++) {
-            float *d = &As[buf][c4 * LDA + i * PPP + t / TPP];
-            d[0] = ra[i].x; d[LDA] = ra[i].y; d[2 * LDA] = ra[i].z; d[3 * LDA] = ra[i].w;
-        }
-#pragma unroll
-        for (int i = 0; i < NPB; i++)
-            *reinterpret_cast<float4 *>(&Bs[buf][(i * RPP + brow) * BN + bcol]) = rb[i];
-    };
+    // Loads are unconditional (out-of-image taps read a valid dummy address and are zeroed when the
+    // registers are written to LDS), so the next chunk's global loads stay in flight across the MFMA loop.
+    float4 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7, rb0, rb1, rb2, rb3;
+    bool ok0 = false, ok1 = false, ok2 = false, ok3 = false, ok4 = false, ok5 = false, ok6 = false, ok7 = false;
+    static_assert(NPA == 4 || NPA == 8 || NPA == 2, "A passes");
+    static_assert(NPB == 4 || NPB == 2 || NPB == 1, "B passes");
+    const float relu_lo = a.relu_in ? 0.f : -INFINITY;      // relu on load folded into one max
+
+#define TMAT_LOAD_A(i, R, OK)                                                                               \
+    if (i < NPA) {                                                                                          \
+        const int yy = py[i] + dy, xx = px[i] + dx;                                                         \
+        OK = pok[i] && yy >= 0 && yy < H && xx >= 0 && xx < W;                                              \
+        const size_t off = OK ? ((size_t)(pbase[i] + (yy >> a.up)) * a.w + (xx >> a.up)) * a.Cin : (size_t)0; \
+        R = *reinterpret_cast<const float4 *>(a.in + off + c0 + c4);                                        \
+    }
+#define TMAT_LOAD_B(i, R) \
+    if (i < NPB) R = *reinterpret_cast<const float4 *>(wp + (size_t)(i * RPP + brow) * a.Cout);
+#define TMAT_LOAD_CHUNK(cc)                                                            \
+    {                                                                                  \
+        const int tap = (cc) / cchunks;                                                \
+        const int c0 = ((cc) - tap * cchunks) * KC;                                    \
+        const int dy = a.ksize == 3 ? tap / 3 - 1 : 0;                                 \
+        const int dx = a.ksize == 3 ? tap % 3 - 1 : 0;                                 \
+        TMAT_LOAD_A(0, ra0, ok0) TMAT_LOAD_A(1, ra1, ok1) TMAT_LOAD_A(2, ra2, ok2) TMAT_LOAD_A(3, ra3, ok3) \
+        TMAT_LOAD_A(4, ra4, ok4) TMAT_LOAD_A(5, ra5, ok5) TMAT_LOAD_A(6, ra6, ok6) TMAT_LOAD_A(7, ra7, ok7) \
+        const float *wp = a.W + ((size_t)tap * a.Cin + c0) * a.Cout + n0 + bcol;       \
+        TMAT_LOAD_B(0, rb0) TMAT_LOAD_B(1, rb1) TMAT_LOAD_B(2, rb2) TMAT_LOAD_B(3, rb3) \
+    }
+#define TMAT_STORE_A(i, R, OK)                                                         \
+    if (i < NPA) {                                                                     \
+        float *d = &As[bb][c4 * LDA + i * PPP + t / TPP];                              \
+        d[0] = OK ? fmaxf(R.x, relu_lo) : 0.f; d[LDA] = OK ? fmaxf(R.y, relu_lo) : 0.f; \
+        d[2 * LDA] = OK ? fmaxf(R.z, relu_lo) : 0.f; d[3 * LDA] = OK ? fmaxf(R.w, relu_lo) : 0.f; \
+    }
+#define TMAT_STORE_B(i, R) \
+    if (i < NPB) *reinterpret_cast<float4 *>(&Bs[bb][(i * RPP + brow) * BN + bcol]) = R;
+#define TMAT_STORE_CHUNK(buf_)                                                         \
+    {                                                                                  \
+        const int bb = (buf_);                                                         \
+        TMAT_STORE_A(0, ra0, ok0) TMAT_STORE_A(1, ra1, ok1) TMAT_STORE_A(2, ra2, ok2) TMAT_STORE_A(3, ra3, ok3) \
+        TMAT_STORE_A(4, ra4, ok4) TMAT_STORE_A(5, ra5, ok5) TMAT_STORE_A(6, ra6, ok6) TMAT_STORE_A(7, ra7, ok7) \
+        TMAT_STORE_B(0, rb0) TMAT_STORE_B(1, rb1) TMAT_STORE_B(2, rb2) TMAT_STORE_B(3, rb3) \
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -121,8 +129,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int M, int H
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][jn][r] = 0.f;
 
-    load_chunk(0);
-    store_chunk(0);
+    TMAT_LOAD_CHUNK(0)
+    TMAT_STORE_CHUNK(0)
     __syncthreads();
 
     const int aoff = (lane >> 5) * LDA + wm * (BM / WM) + (lane & 31);
@@ -130,7 +138,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int M, int H
 
     for (int c = 0; c < nchunks; c++) {
         const int buf = c & 1;
-        if (c + 1 < nchunks) load_chunk(c + 1);
+        // prefetch the next chunk (the last iteration re-loads the last chunk; it is never consumed)
+        const int cn = c + 1 < nchunks ? c + 1 : c;
+        TMAT_LOAD_CHUNK(cn)
+        __builtin_amdgcn_sched_barrier(0);      // keep the LDS-store math of the prefetched chunk below the MFMA loop
         const float *Ab = &As[buf][aoff];
         const float *Bb = &Bs[buf][boff];
 #pragma unroll
@@ -146,9 +157,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int M, int H
                 for (int jn = 0; jn < TN; jn++)
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[jn], acc[i][jn], 0, 0, 0);
         }
-        if (c + 1 < nchunks) store_chunk(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        TMAT_STORE_CHUNK(buf ^ 1)
         __syncthreads();
     }
+#undef TMAT_LOAD_A
+#undef TMAT_LOAD_B
+#undef TMAT_LOAD_CHUNK
+#undef TMAT_STORE_A
+#undef TMAT_STORE_B
+#undef TMAT_STORE_CHUNK
 
     // epilogue: C/D layout col = lane & 31 (cout), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (pixel)
     const int rH = Ho >> a.rs, rW = Wo >> a.rs;
