@@ -38,8 +38,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int M, int H
     constexpr int NPB = KC / RPP;        // B passes
     static_assert(NPA >= 1 && NPB >= 1, "tile config");
 
-    __shared__ float As[2][KC * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][KC * BN];
+    // one LDS array: [2][KC*BN] weight chunks (16-byte aligned), then [2][KC*LDA] pixel chunks; the epilogue
+    // reuses it as a [128][BN] output staging tile
+    constexpr int EPR = 128;
+    constexpr int SM_MAIN = 2 * KC * BN + 2 * KC * LDA;
+    constexpr int SM = SM_MAIN > EPR * BN ? SM_MAIN : EPR * BN;
+    __shared__ __attribute__((aligned(16))) float smem[SM];
+    float(*Bs)[KC * BN] = reinterpret_cast<float(*)[KC * BN]>(smem);
+    float(*As)[KC * LDA] = reinterpret_cast<float(*)[KC * LDA]>(smem + 2 * KC * BN);
 
     // XCD-aware tile mapping: blocks b and b+8 share an XCD (round-robin dispatch); give the
     // nNt column tiles of one pixel tile to the same XCD so its L2 serves the re-read A pixels.
@@ -168,31 +174,57 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int M, int H
 #undef TMAT_STORE_B
 #undef TMAT_STORE_CHUNK
 
-    // epilogue: C/D layout col = lane & 31 (cout), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (pixel)
-    const int rH = Ho >> a.rs, rW = Wo >> a.rs;
+    // epilogue: accumulators -> LDS tile [128][BN] (C/D layout: col = lane & 31 is the output channel,
+    // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) the pixel) -> BN fold / bias, residual, ReLU on float4 rows ->
+    // 16-byte coalesced stores (one wave writes 1 KiB contiguous).
+    {
+        constexpr int NPASS = BM / EPR;
+        constexpr int V4 = BN / 4;
+        constexpr int RPI = 256 / V4;            // rows per store iteration
+        float *Cs = smem;
+        const int cv = (t % V4) * 4, r0 = t / V4;
+        const int co = n0 + cv;
+        float4 sc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 sh = *reinterpret_cast<const float4 *>(a.shift + co);
+        if (a.scale) sc = *reinterpret_cast<const float4 *>(a.scale + co);
+        const int rH = Ho >> a.rs, rW = Wo >> a.rs;
+        const int wrow0 = wm * (BM / WM);
 #pragma unroll
-    for (int i = 0; i < TM; i++) {
+        for (int pass = 0; pass < NPASS; pass++) {
+            if (wrow0 / EPR == pass) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int m = m0 + wm * (BM / WM) + i * 32 + row;
-            if (m >= M) continue;
-            size_t ridx = (size_t)m;
-            if (a.resid && a.rs) {
-                int n = m / (Ho * Wo);
-                int rr = m - n * (Ho * Wo);
-                int y = rr / Wo, x = rr - y * Wo;
-                ridx = ((size_t)n * rH + (y >> a.rs)) * rW + (x >> a.rs);
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int row = wrow0 % EPR + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+                        for (int jn = 0; jn < TN; jn++) Cs[row * BN + wn * (BN / WN) + jn * 32 + (lane & 31)] = acc[i][jn][r];
+                    }
             }
-#pragma unroll
-            for (int jn = 0; jn < TN; jn++) {
-                const int co = n0 + wn * (BN / WN) + jn * 32 + (lane & 31);
-                float v = acc[i][jn][r];
-                v = a.scale ? fmaf(v, a.scale[co], a.shift[co]) : v + a.shift[co];
-                if (a.resid) v = v + a.resid[ridx * a.Cout + co];
-                if (a.relu_out) v = fmaxf(v, 0.f);
-                a.out[(size_t)m * a.Cout + co] = v;
+            __syncthreads();
+#pragma unroll 4
+            for (int it = 0; it < EPR / RPI; it++) {
+                const int row = it * RPI + r0;
+                const int m = m0 + pass * EPR + row;
+                if (m >= M) continue;
+                float4 v = *reinterpret_cast<const float4 *>(Cs + row * BN + cv);
+                if (a.scale) { v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w); }
+                else { v.x = v.x + sh.x; v.y = v.y + sh.y; v.z = v.z + sh.z; v.w = v.w + sh.w; }
+                if (a.resid) {
+                    size_t ridx = (size_t)m;
+                    if (a.rs) {
+                        const int n = m / (Ho * Wo);
+                        const int rr = m - n * (Ho * Wo);
+                        const int y = rr / Wo, x = rr - y * Wo;
+                        ridx = ((size_t)n * rH + (y >> a.rs)) * rW + (x >> a.rs);
+                    }
+                    const float4 rv = *reinterpret_cast<const float4 *>(a.resid + ridx * a.Cout + co);
+                    v.x = v.x + rv.x; v.y = v.y + rv.y; v.z = v.z + rv.z; v.w = v.w + rv.w;
+                }
+                if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4 *>(a.out + (size_t)m * a.Cout + co) = v;
             }
+            if (pass + 1 < NPASS) __syncthreads();
         }
     }
 }
@@ -227,121 +259,117 @@ bool launch_conv(const ConvArgs &a, hipStream_t s)
 // depthwise 3x3 (SeparableConv2D's depthwise half, models.py:131,135): chain over the 9 taps in
 // (ky, kx) order, zero padding, optional ReLU on load.  One thread = one pixel x 4 channels.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dwconv_kernel(const float *__restrict__ in, int N, int H, int W, int C,
-                                                     int relu_in, const float *__restrict__ Wd, float *__restrict__ out,
-                                                     size_t total4)
+__global__ __launch_bounds__(256) void dwconv_kernel(const float *__restrict__ in, int H, int W, int C, int c4shift,
+                                                     int relu_in, const float *__restrict__ Wd, float *__restrict__ out)
 {
-    const int C4 = C >> 2;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (size_t)gridDim.x * blockDim.x) {
-        int cq = (int)(idx % C4);
-        size_t p = idx / C4;
-        int x = (int)(p % W);
-        size_t q = p / W;
-        int y = (int)(q % H);
-        int n = (int)(q / H);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // grid: (ceil(H*W*C4 / 256), N); all index math in 32 bits, C4 = C/4 is a power of two
+    const int n = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;          // element = pixel * C4 + cq
+    const int C4 = 1 << c4shift;
+    const int cq = e & (C4 - 1);
+    const int p = e >> c4shift;
+    if (p >= H * W) return;
+    const int y = p / W, x = p - y * W;
+    const float *base = in + (size_t)n * H * W * C + cq * 4;
+    const float lo = relu_in ? 0.f : -INFINITY;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int tp = 0; tp < 9; tp++) {
-            int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-                v = *reinterpret_cast<const float4 *>(in + (((size_t)n * H + yy) * W + xx) * C + cq * 4);
-                if (relu_in) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            }
-            float4 w = *reinterpret_cast<const float4 *>(Wd + tp * C + cq * 4);
-            acc.x = fmaf(v.x, w.x, acc.x); acc.y = fmaf(v.y, w.y, acc.y);
-            acc.z = fmaf(v.z, w.z, acc.z); acc.w = fmaf(v.w, w.w, acc.w);
-        }
-        *reinterpret_cast<float4 *>(out + idx * 4) = acc;
+    for (int tp = 0; tp < 9; tp++) {
+        const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+        float4 v = *reinterpret_cast<const float4 *>(base + (ok ? (yy * W + xx) * C : 0));
+        v.x = ok ? fmaxf(v.x, lo) : 0.f; v.y = ok ? fmaxf(v.y, lo) : 0.f;
+        v.z = ok ? fmaxf(v.z, lo) : 0.f; v.w = ok ? fmaxf(v.w, lo) : 0.f;
+        const float4 w = *reinterpret_cast<const float4 *>(Wd + tp * C + cq * 4);
+        acc.x = fmaf(v.x, w.x, acc.x); acc.y = fmaf(v.y, w.y, acc.y);
+        acc.z = fmaf(v.z, w.z, acc.z); acc.w = fmaf(v.w, w.w, acc.w);
     }
+    *reinterpret_cast<float4 *>(out + ((size_t)n * H * W + p) * C + cq * 4) = acc;
 }
+
+static int ilog2(int v) { int s = 0; while ((1 << s) < v) s++; return s; }
 
 void launch_dwconv(const float *in, int N, int H, int W, int C, int relu_in, const float *Wd, float *out, hipStream_t s)
 {
-    size_t total4 = (size_t)N * H * W * (C / 4);
-    int grid = (int)((total4 + 255) / 256 < 16384 ? (total4 + 255) / 256 : 16384);
-    hipLaunchKernelGGL(dwconv_kernel, dim3(grid), dim3(256), 0, s, in, N, H, W, C, relu_in, Wd, out, total4);
+    const int C4 = C / 4;
+    const int total = H * W * C4;
+    hipLaunchKernelGGL(dwconv_kernel, dim3((total + 255) / 256, N), dim3(256), 0, s, in, H, W, C, ilog2(C4), relu_in, Wd, out);
 }
 
 // ---------------------------------------------------------------------------------------------
 // stem: Conv2D(C, 3, strides=2, "same") + BN + ReLU on the single-channel patch (models.py:119-121).
 // TF SAME with even H: taps read rows 2y .. 2y+2 (zero beyond the image).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ x, int N, int H, int W,
-                                                   const float *__restrict__ Ws, int Cout,
-                                                   const float *__restrict__ scale, const float *__restrict__ shift,
-                                                   float *__restrict__ out, size_t total4)
+__global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ x, int H, int W, const float *__restrict__ Ws,
+                                                   int Cout, int c4shift, const float *__restrict__ scale,
+                                                   const float *__restrict__ shift, float *__restrict__ out)
 {
-    const int Ho = H >> 1, Wo = W >> 1, C4 = Cout >> 2;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (size_t)gridDim.x * blockDim.x) {
-        int cq = (int)(idx % C4);
-        size_t p = idx / C4;
-        int xo = (int)(p % Wo);
-        size_t q = p / Wo;
-        int yo = (int)(q % Ho);
-        int n = (int)(q / Ho);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int n = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int cq = e & ((1 << c4shift) - 1);
+    const int p = e >> c4shift;
+    if (p >= Ho * Wo) return;
+    const int yo = p / Wo, xo = p - yo * Wo;
+    const float *xin = x + (size_t)n * H * W;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int tp = 0; tp < 9; tp++) {
-            int iy = 2 * yo + tp / 3, ix = 2 * xo + tp % 3;
-            float v = (iy < H && ix < W) ? x[((size_t)n * H + iy) * W + ix] : 0.f;
-            float4 w = *reinterpret_cast<const float4 *>(Ws + tp * Cout + cq * 4);
-            acc.x = fmaf(v, w.x, acc.x); acc.y = fmaf(v, w.y, acc.y);
-            acc.z = fmaf(v, w.z, acc.z); acc.w = fmaf(v, w.w, acc.w);
-        }
-        float4 sc = *reinterpret_cast<const float4 *>(scale + cq * 4);
-        float4 sh = *reinterpret_cast<const float4 *>(shift + cq * 4);
-        float4 o;
-        o.x = fmaxf(fmaf(acc.x, sc.x, sh.x), 0.f); o.y = fmaxf(fmaf(acc.y, sc.y, sh.y), 0.f);
-        o.z = fmaxf(fmaf(acc.z, sc.z, sh.z), 0.f); o.w = fmaxf(fmaf(acc.w, sc.w, sh.w), 0.f);
-        *reinterpret_cast<float4 *>(out + idx * 4) = o;
+    for (int tp = 0; tp < 9; tp++) {
+        const int iy = 2 * yo + tp / 3, ix = 2 * xo + tp % 3;
+        const float v = (iy < H && ix < W) ? xin[iy * W + ix] : 0.f;
+        const float4 w = *reinterpret_cast<const float4 *>(Ws + tp * Cout + cq * 4);
+        acc.x = fmaf(v, w.x, acc.x); acc.y = fmaf(v, w.y, acc.y);
+        acc.z = fmaf(v, w.z, acc.z); acc.w = fmaf(v, w.w, acc.w);
     }
+    const float4 sc = *reinterpret_cast<const float4 *>(scale + cq * 4);
+    const float4 sh = *reinterpret_cast<const float4 *>(shift + cq * 4);
+    float4 o;
+    o.x = fmaxf(fmaf(acc.x, sc.x, sh.x), 0.f); o.y = fmaxf(fmaf(acc.y, sc.y, sh.y), 0.f);
+    o.z = fmaxf(fmaf(acc.z, sc.z, sh.z), 0.f); o.w = fmaxf(fmaf(acc.w, sc.w, sh.w), 0.f);
+    *reinterpret_cast<float4 *>(out + ((size_t)n * Ho * Wo + p) * Cout + cq * 4) = o;
 }
 
 void launch_stem(const float *x, int N, int H, int W, const float *Ws, int Cout, const float *scale,
                  const float *shift, float *out, hipStream_t s)
 {
-    size_t total4 = (size_t)N * (H / 2) * (W / 2) * (Cout / 4);
-    int grid = (int)((total4 + 255) / 256 < 16384 ? (total4 + 255) / 256 : 16384);
-    hipLaunchKernelGGL(stem_kernel, dim3(grid), dim3(256), 0, s, x, N, H, W, Ws, Cout, scale, shift, out, total4);
+    const int total = (H / 2) * (W / 2) * (Cout / 4);
+    hipLaunchKernelGGL(stem_kernel, dim3((total + 255) / 256, N), dim3(256), 0, s, x, H, W, Ws, Cout, ilog2(Cout / 4), scale, shift, out);
 }
 
 // ---------------------------------------------------------------------------------------------
 // MaxPooling2D(3, strides=2, "same") + residual add (models.py:138-144)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void maxpool_add_kernel(const float *__restrict__ p2, int N, int H, int W, int C,
-                                                          const float *__restrict__ r, float *__restrict__ out,
-                                                          size_t total4)
+__global__ __launch_bounds__(256) void maxpool_add_kernel(const float *__restrict__ p2, int H, int W, int C, int c4shift,
+                                                          const float *__restrict__ r, float *__restrict__ out)
 {
-    const int Ho = H >> 1, Wo = W >> 1, C4 = C >> 2;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total4; idx += (size_t)gridDim.x * blockDim.x) {
-        int cq = (int)(idx % C4);
-        size_t p = idx / C4;
-        int xo = (int)(p % Wo);
-        size_t q = p / Wo;
-        int yo = (int)(q % Ho);
-        int n = (int)(q / Ho);
-        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int n = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int cq = e & ((1 << c4shift) - 1);
+    const int p = e >> c4shift;
+    if (p >= Ho * Wo) return;
+    const int yo = p / Wo, xo = p - yo * Wo;
+    const float *base = p2 + (size_t)n * H * W * C + cq * 4;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
 #pragma unroll
-        for (int tp = 0; tp < 9; tp++) {
-            int iy = 2 * yo + tp / 3, ix = 2 * xo + tp % 3;
-            if (iy < H && ix < W) {
-                float4 v = *reinterpret_cast<const float4 *>(p2 + (((size_t)n * H + iy) * W + ix) * C + cq * 4);
-                m.x = v.x > m.x ? v.x : m.x; m.y = v.y > m.y ? v.y : m.y;
-                m.z = v.z > m.z ? v.z : m.z; m.w = v.w > m.w ? v.w : m.w;
-            }
+    for (int tp = 0; tp < 9; tp++) {
+        const int iy = 2 * yo + tp / 3, ix = 2 * xo + tp % 3;
+        if (iy < H && ix < W) {
+            const float4 v = *reinterpret_cast<const float4 *>(base + (iy * W + ix) * C);
+            m.x = v.x > m.x ? v.x : m.x; m.y = v.y > m.y ? v.y : m.y;
+            m.z = v.z > m.z ? v.z : m.z; m.w = v.w > m.w ? v.w : m.w;
         }
-        float4 rv = *reinterpret_cast<const float4 *>(r + idx * 4);
-        m.x = m.x + rv.x; m.y = m.y + rv.y; m.z = m.z + rv.z; m.w = m.w + rv.w;
-        *reinterpret_cast<float4 *>(out + idx * 4) = m;
     }
+    const size_t o = ((size_t)n * Ho * Wo + p) * C + cq * 4;
+    const float4 rv = *reinterpret_cast<const float4 *>(r + o);
+    m.x = m.x + rv.x; m.y = m.y + rv.y; m.z = m.z + rv.z; m.w = m.w + rv.w;
+    *reinterpret_cast<float4 *>(out + o) = m;
 }
 
 void launch_maxpool_add(const float *p2, int N, int H, int W, int C, const float *r, float *out, hipStream_t s)
 {
-    size_t total4 = (size_t)N * (H / 2) * (W / 2) * (C / 4);
-    int grid = (int)((total4 + 255) / 256 < 16384 ? (total4 + 255) / 256 : 16384);
-    hipLaunchKernelGGL(maxpool_add_kernel, dim3(grid), dim3(256), 0, s, p2, N, H, W, C, r, out, total4);
+    const int total = (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool_add_kernel, dim3((total + 255) / 256, N), dim3(256), 0, s, p2, H, W, C, ilog2(C / 4), r, out);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -365,40 +393,56 @@ __device__ __forceinline__ float exp_det(float x)
     return ldexpf(y, (int)n);
 }
 
-__global__ __launch_bounds__(256) void final_kernel(const float *__restrict__ S, int N, int h, int w, int C,
+// One block = 32 x 8 output pixels of one patch.  The (6 x 18) low-resolution pixels they touch are staged in LDS
+// (pixel stride padded to C + 4 floats so the 16-byte channel reads of neighbouring pixels do not collide), weights in LDS.
+__global__ __launch_bounds__(256) void final_kernel(const float *__restrict__ S, int h, int w, int C,
                                                     const float *__restrict__ Wf, float bias, float *__restrict__ out)
 {
-    extern __shared__ float wsh[];   // [9][C]
-    for (int i = threadIdx.x; i < 9 * C; i += 256) wsh[i] = Wf[i];
-    __syncthreads();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int CP = C + 4;
+    float *wsh = smem;                       // [9][C]
+    float *tile = smem + 9 * C;              // [6][18][CP]
     const int H = 2 * h, W = 2 * w;
-    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
     const int n = blockIdx.z;
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 8;
+    const int ly0 = (y0 - 1) >> 1, lx0 = (x0 - 1) >> 1;     // floor division also for -1
+    for (int i = threadIdx.x; i < 9 * C; i += 256) wsh[i] = Wf[i];
+    const int C4 = C >> 2;
+    for (int i = threadIdx.x; i < 6 * 18 * C4; i += 256) {
+        const int cq = i % C4, p = i / C4;
+        const int ly = ly0 + p / 18, lx = lx0 + p % 18;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ly >= 0 && ly < h && lx >= 0 && lx < w) v = *reinterpret_cast<const float4 *>(S + (((size_t)n * h + ly) * w + lx) * C + cq * 4);
+        *reinterpret_cast<float4 *>(tile + p * CP + cq * 4) = v;
+    }
+    __syncthreads();
+    const int x = x0 + (threadIdx.x & 31), y = y0 + (threadIdx.x >> 5);
     if (x >= W || y >= H) return;
     float acc = 0.f;
     for (int tp = 0; tp < 9; tp++) {
-        int iy = y + tp / 3 - 1, ix = x + tp % 3 - 1;
+        const int iy = y + tp / 3 - 1, ix = x + tp % 3 - 1;
         const float *wr = wsh + tp * C;
         if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-            const float *ip = S + (((size_t)n * h + (iy >> 1)) * w + (ix >> 1)) * C;
+            const float *ip = tile + (((iy >> 1) - ly0) * 18 + ((ix >> 1) - lx0)) * CP;
             for (int c = 0; c < C; c += 4) {
-                float4 v = *reinterpret_cast<const float4 *>(ip + c);
-                acc = fmaf(v.x, wr[c], acc); acc = fmaf(v.y, wr[c + 1], acc);
-                acc = fmaf(v.z, wr[c + 2], acc); acc = fmaf(v.w, wr[c + 3], acc);
+                const float4 v = *reinterpret_cast<const float4 *>(ip + c);
+                const float4 ww = *reinterpret_cast<const float4 *>(wr + c);
+                acc = fmaf(v.x, ww.x, acc); acc = fmaf(v.y, ww.y, acc);
+                acc = fmaf(v.z, ww.z, acc); acc = fmaf(v.w, ww.w, acc);
             }
         } else {
             for (int c = 0; c < C; c++) acc = fmaf(0.f, wr[c], acc);
         }
     }
-    float z = acc + bias;
+    const float z = acc + bias;
     out[((size_t)n * H + y) * W + x] = 1.0f / (1.0f + exp_det(-z));
 }
 
 void launch_final(const float *S, int N, int h, int w, int C, const float *Wf, float bias, float *out, hipStream_t s)
 {
     dim3 grid((2 * w + 31) / 32, (2 * h + 7) / 8, N);
-    hipLaunchKernelGGL(final_kernel, grid, dim3(256), 9 * C * sizeof(float), s, S, N, h, w, C, Wf, bias, out);
+    const size_t lds = (size_t)(9 * C + 6 * 18 * (C + 4)) * sizeof(float);
+    hipLaunchKernelGGL(final_kernel, grid, dim3(256), lds, s, S, h, w, C, Wf, bias, out);
 }
 
 }  // namespace tmat
