@@ -147,7 +147,7 @@ static bool build_model(Ctx *c, const std::map<std::string, Tensor> &m)
     c->f_last = cin;
     if (c->down.size() != c->up.size() - 1 || c->down.empty()) { set_error("weights: unexpected block structure"); return false; }
     int P = c->patch;
-    if (P % (2 << c->down.size()) || P <= 0) { set_error("weights: patch size must be divisible by 2^(blocks+1)"); return false; }
+    if (P % (8 << c->down.size()) || P <= 0) { set_error("weights: patch size must be divisible by 2^(blocks+1)"); return false; }
     return true;
 }
 

@@ -85,8 +85,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int M, int H
 
     // Loads are unconditional (out-of-image taps read a valid dummy address and are zeroed when the
     // registers are written to LDS), so the next chunk's global loads stay in flight across the MFMA loop.
-    float4 ra0, ra1, ra2, ra3, ra4, ra5, ra6, ra7, rb0, rb1, rb2, rb3;
-    bool ok0 = false, ok1 = false, ok2 = false, ok3 = false, ok4 = false, ok5 = false, ok6 = false, ok7 = false;
+    // Two register sets (P, Q) hold the chunks c+1 and c+2 while chunk c is multiplied: a chunk's global loads
+    // have two MFMA phases (~8k cycles) to land before they are written to LDS.
+    float4 pa0, pa1, pa2, pa3, pa4, pa5, pa6, pa7, pb0, pb1, pb2, pb3;
+    float4 qa0, qa1, qa2, qa3, qa4, qa5, qa6, qa7, qb0, qb1, qb2, qb3;
+    bool pk0 = false, pk1 = false, pk2 = false, pk3 = false, pk4 = false, pk5 = false, pk6 = false, pk7 = false;
+    bool qk0 = false, qk1 = false, qk2 = false, qk3 = false, qk4 = false, qk5 = false, qk6 = false, qk7 = false;
     static_assert(NPA == 4 || NPA == 8 || NPA == 2, "A passes");
     static_assert(NPB == 4 || NPB == 2 || NPB == 1, "B passes");
     const float relu_lo = a.relu_in ? 0.f : -INFINITY;      // relu on load folded into one max
@@ -100,16 +104,17 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int M, int H
     }
 #define TMAT_LOAD_B(i, R) \
     if (i < NPB) R = *reinterpret_cast<const float4 *>(wp + (size_t)(i * RPP + brow) * a.Cout);
-#define TMAT_LOAD_CHUNK(cc)                                                            \
+#define TMAT_LOAD_CHUNK(cc_, S)                                                        \
     {                                                                                  \
-        const int tap = (cc) / cchunks;                                                \
-        const int c0 = ((cc) - tap * cchunks) * KC;                                    \
+        const int cc = (cc_) < nchunks ? (cc_) : nchunks - 1;                          \
+        const int tap = cc / cchunks;                                                  \
+        const int c0 = (cc - tap * cchunks) * KC;                                      \
         const int dy = a.ksize == 3 ? tap / 3 - 1 : 0;                                 \
         const int dx = a.ksize == 3 ? tap % 3 - 1 : 0;                                 \
-        TMAT_LOAD_A(0, ra0, ok0) TMAT_LOAD_A(1, ra1, ok1) TMAT_LOAD_A(2, ra2, ok2) TMAT_LOAD_A(3, ra3, ok3) \
-        TMAT_LOAD_A(4, ra4, ok4) TMAT_LOAD_A(5, ra5, ok5) TMAT_LOAD_A(6, ra6, ok6) TMAT_LOAD_A(7, ra7, ok7) \
+        TMAT_LOAD_A(0, S##a0, S##k0) TMAT_LOAD_A(1, S##a1, S##k1) TMAT_LOAD_A(2, S##a2, S##k2) TMAT_LOAD_A(3, S##a3, S##k3) \
+        TMAT_LOAD_A(4, S##a4, S##k4) TMAT_LOAD_A(5, S##a5, S##k5) TMAT_LOAD_A(6, S##a6, S##k6) TMAT_LOAD_A(7, S##a7, S##k7) \
         const float *wp = a.W + ((size_t)tap * a.Cin + c0) * a.Cout + n0 + bcol;       \
-        TMAT_LOAD_B(0, rb0) TMAT_LOAD_B(1, rb1) TMAT_LOAD_B(2, rb2) TMAT_LOAD_B(3, rb3) \
+        TMAT_LOAD_B(0, S##b0) TMAT_LOAD_B(1, S##b1) TMAT_LOAD_B(2, S##b2) TMAT_LOAD_B(3, S##b3) \
     }
 #define TMAT_STORE_A(i, R, OK)                                                         \
     if (i < NPA) {                                                                     \
@@ -119,12 +124,25 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int M, int H
     }
 #define TMAT_STORE_B(i, R) \
     if (i < NPB) *reinterpret_cast<float4 *>(&Bs[bb][(i * RPP + brow) * BN + bcol]) = R;
-#define TMAT_STORE_CHUNK(buf_)                                                         \
+#define TMAT_STORE_CHUNK(buf_, S)                                                      \
     {                                                                                  \
         const int bb = (buf_);                                                         \
-        TMAT_STORE_A(0, ra0, ok0) TMAT_STORE_A(1, ra1, ok1) TMAT_STORE_A(2, ra2, ok2) TMAT_STORE_A(3, ra3, ok3) \
-        TMAT_STORE_A(4, ra4, ok4) TMAT_STORE_A(5, ra5, ok5) TMAT_STORE_A(6, ra6, ok6) TMAT_STORE_A(7, ra7, ok7) \
-        TMAT_STORE_B(0, rb0) TMAT_STORE_B(1, rb1) TMAT_STORE_B(2, rb2) TMAT_STORE_B(3, rb3) \
+        TMAT_STORE_A(0, S##a0, S##k0) TMAT_STORE_A(1, S##a1, S##k1) TMAT_STORE_A(2, S##a2, S##k2) TMAT_STORE_A(3, S##a3, S##k3) \
+        TMAT_STORE_A(4, S##a4, S##k4) TMAT_STORE_A(5, S##a5, S##k5) TMAT_STORE_A(6, S##a6, S##k6) TMAT_STORE_A(7, S##a7, S##k7) \
+        TMAT_STORE_B(0, S##b0) TMAT_STORE_B(1, S##b1) TMAT_STORE_B(2, S##b2) TMAT_STORE_B(3, S##b3) \
+    }
+#define TMAT_MFMA_CHUNK(buf_)                                                          \
+    {                                                                                  \
+        const float *Ab = &As[buf_][aoff];                                             \
+        const float *Bb = &Bs[buf_][boff];                                             \
+        _Pragma("unroll") for (int kk = 0; kk < KC / 2; kk++) {                        \
+            float av[TM], bv[TN];                                                      \
+            _Pragma("unroll") for (int i = 0; i < TM; i++) av[i] = Ab[kk * 2 * LDA + i * 32];   \
+            _Pragma("unroll") for (int jn = 0; jn < TN; jn++) bv[jn] = Bb[kk * 2 * BN + jn * 32]; \
+            _Pragma("unroll") for (int i = 0; i < TM; i++)                             \
+                _Pragma("unroll") for (int jn = 0; jn < TN; jn++)                      \
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[jn], acc[i][jn], 0, 0, 0); \
+        }                                                                              \
     }
 
     f32x16 acc[TM][TN];
@@ -135,36 +153,27 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int M, int H
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][jn][r] = 0.f;
 
-    TMAT_LOAD_CHUNK(0)
-    TMAT_STORE_CHUNK(0)
-    __syncthreads();
-
     const int aoff = (lane >> 5) * LDA + wm * (BM / WM) + (lane & 31);
     const int boff = (lane >> 5) * BN + wn * (BN / WN) + (lane & 31);
 
-    for (int c = 0; c < nchunks; c++) {
-        const int buf = c & 1;
-        // prefetch the next chunk (the last iteration re-loads the last chunk; it is never consumed)
-        const int cn = c + 1 < nchunks ? c + 1 : c;
-        TMAT_LOAD_CHUNK(cn)
-        __builtin_amdgcn_sched_barrier(0);      // keep the LDS-store math of the prefetched chunk below the MFMA loop
-        const float *Ab = &As[buf][aoff];
-        const float *Bb = &Bs[buf][boff];
-#pragma unroll
-        for (int kk = 0; kk < KC / 2; kk++) {
-            float av[TM], bv[TN];
-#pragma unroll
-            for (int i = 0; i < TM; i++) av[i] = Ab[kk * 2 * LDA + i * 32];
-#pragma unroll
-            for (int jn = 0; jn < TN; jn++) bv[jn] = Bb[kk * 2 * BN + jn * 32];
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int jn = 0; jn < TN; jn++)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[jn], acc[i][jn], 0, 0, 0);
-        }
+    TMAT_LOAD_CHUNK(0, p)
+    TMAT_STORE_CHUNK(0, p)
+    TMAT_LOAD_CHUNK(1, q)
+    __syncthreads();
+
+    // chunk c lives in LDS buffer c & 1; register set p carries even chunks, q odd ones (nchunks is even: host check)
+    for (int c = 0; c < nchunks; c += 2) {
+        TMAT_LOAD_CHUNK(c + 2, p)
+        __builtin_amdgcn_sched_barrier(0);      // keep the staging math of prefetched chunks out of the MFMA loop
+        TMAT_MFMA_CHUNK(0)
         __builtin_amdgcn_sched_barrier(0);
-        TMAT_STORE_CHUNK(buf ^ 1)
+        TMAT_STORE_CHUNK(1, q)                  // chunk c + 1
+        __syncthreads();
+        TMAT_LOAD_CHUNK(c + 3, q)
+        __builtin_amdgcn_sched_barrier(0);
+        TMAT_MFMA_CHUNK(1)
+        __builtin_amdgcn_sched_barrier(0);
+        TMAT_STORE_CHUNK(0, p)                  // chunk c + 2
         __syncthreads();
     }
 #undef TMAT_LOAD_A
@@ -173,6 +182,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int M, int H
 #undef TMAT_STORE_A
 #undef TMAT_STORE_B
 #undef TMAT_STORE_CHUNK
+#undef TMAT_MFMA_CHUNK
 
     // epilogue: accumulators -> LDS tile [128][BN] (C/D layout: col = lane & 31 is the output channel,
     // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) the pixel) -> BN fold / bias, residual, ReLU on float4 rows ->
@@ -243,7 +253,7 @@ bool launch_conv(const ConvArgs &a, hipStream_t s)
     const int Ho = H / a.stride, Wo = W / a.stride;
     const long long Mll = (long long)a.N * Ho * Wo;
     if (!((a.ksize == 3 && a.stride == 1) || (a.ksize == 1 && (a.stride == 1 || a.stride == 2))) || a.Cin % 32 ||
-        a.Cout % 64 || Mll <= 0 || Mll > 0x7fffffffLL / 2 || (a.resid && a.rs && ((Ho | Wo) & 1))) {
+        a.Cout % 64 || ((a.ksize * a.ksize * (a.Cin / (a.Cout % 128 == 0 ? 32 : 16))) & 1) || Mll <= 0 || Mll > 0x7fffffffLL / 2 || (a.resid && a.rs && ((Ho | Wo) & 1))) {
         set_error("launch_conv: unsupported shape");
         return false;
     }
@@ -262,29 +272,45 @@ bool launch_conv(const ConvArgs &a, hipStream_t s)
 __global__ __launch_bounds__(256) void dwconv_kernel(const float *__restrict__ in, int H, int W, int C, int c4shift,
                                                      int relu_in, const float *__restrict__ Wd, float *__restrict__ out)
 {
-    // grid: (ceil(H*W*C4 / 256), N); all index math in 32 bits, C4 = C/4 is a power of two
+    // grid: (ceil(H * (W/4) * C4 / 256), N).  One thread = 4 consecutive pixels of a row x 4 channels: the 3 x 6
+    // input window is loaded once (18 float4 instead of 36).  32-bit index math; C4 = C/4 is a power of two.
     const int n = blockIdx.y;
-    const int e = blockIdx.x * 256 + threadIdx.x;          // element = pixel * C4 + cq
+    const int e = blockIdx.x * 256 + threadIdx.x;
     const int C4 = 1 << c4shift;
     const int cq = e & (C4 - 1);
-    const int p = e >> c4shift;
-    if (p >= H * W) return;
-    const int y = p / W, x = p - y * W;
+    const int g = e >> c4shift;                 // pixel group index
+    const int WG = W >> 2;
+    if (g >= H * WG) return;
+    const int y = g / WG, x0 = (g - y * WG) * 4;
     const float *base = in + (size_t)n * H * W * C + cq * 4;
     const float lo = relu_in ? 0.f : -INFINITY;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 win[3][6];
 #pragma unroll
-    for (int tp = 0; tp < 9; tp++) {
-        const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
-        const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-        float4 v = *reinterpret_cast<const float4 *>(base + (ok ? (yy * W + xx) * C : 0));
-        v.x = ok ? fmaxf(v.x, lo) : 0.f; v.y = ok ? fmaxf(v.y, lo) : 0.f;
-        v.z = ok ? fmaxf(v.z, lo) : 0.f; v.w = ok ? fmaxf(v.w, lo) : 0.f;
-        const float4 w = *reinterpret_cast<const float4 *>(Wd + tp * C + cq * 4);
-        acc.x = fmaf(v.x, w.x, acc.x); acc.y = fmaf(v.y, w.y, acc.y);
-        acc.z = fmaf(v.z, w.z, acc.z); acc.w = fmaf(v.w, w.w, acc.w);
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            const int yy = y + r - 1, xx = x0 + c - 1;
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            float4 v = *reinterpret_cast<const float4 *>(base + (ok ? (yy * W + xx) * C : 0));
+            v.x = ok ? fmaxf(v.x, lo) : 0.f; v.y = ok ? fmaxf(v.y, lo) : 0.f;
+            v.z = ok ? fmaxf(v.z, lo) : 0.f; v.w = ok ? fmaxf(v.w, lo) : 0.f;
+            win[r][c] = v;
+        }
+    float4 wt[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; tp++) wt[tp] = *reinterpret_cast<const float4 *>(Wd + tp * C + cq * 4);
+    float *obase = out + ((size_t)n * H * W + (size_t)y * W + x0) * C + cq * 4;
+#pragma unroll
+    for (int px = 0; px < 4; px++) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int tp = 0; tp < 9; tp++) {
+            const float4 v = win[tp / 3][px + tp % 3];
+            acc.x = fmaf(v.x, wt[tp].x, acc.x); acc.y = fmaf(v.y, wt[tp].y, acc.y);
+            acc.z = fmaf(v.z, wt[tp].z, acc.z); acc.w = fmaf(v.w, wt[tp].w, acc.w);
+        }
+        *reinterpret_cast<float4 *>(obase + px * C) = acc;
     }
-    *reinterpret_cast<float4 *>(out + ((size_t)n * H * W + p) * C + cq * 4) = acc;
 }
 
 static int ilog2(int v) { int s = 0; while ((1 << s) < v) s++; return s; }
@@ -292,7 +318,7 @@ static int ilog2(int v) { int s = 0; while ((1 << s) < v) s++; return s; }
 void launch_dwconv(const float *in, int N, int H, int W, int C, int relu_in, const float *Wd, float *out, hipStream_t s)
 {
     const int C4 = C / 4;
-    const int total = H * W * C4;
+    const int total = H * (W / 4) * C4;         // W % 4 == 0 for every level of the model (checked in tmat_create)
     hipLaunchKernelGGL(dwconv_kernel, dim3((total + 255) / 256, N), dim3(256), 0, s, in, H, W, C, ilog2(C4), relu_in, Wd, out);
 }
 
