@@ -71,6 +71,36 @@ static int enqueue_segment(Ctx *c, const uint16_t *imgs_dev, int k, int slot)
     return TMAT_OK;
 }
 
+// Two-stream form used by tmat_analyze_batch*: the memory-bound front half of pass p+1 (Lanczos, rescale, tile
+// gather, UNet down path) runs on stream2 while the MFMA-bound back half of pass p (UNet up path, final conv, blend,
+// D2H) runs on the main stream.
+static int enqueue_front(Ctx *c, const uint16_t *imgs_dev, int k, int slot, const TileGeom &g)
+{
+    PassBuf &b = c->pass;
+    hipStream_t s = c->stream2;
+    launch_lanczos(imgs_dev, k, b.H, b.W, b.h, b.w, b.xi, b.xc, b.yi, b.yc, b.tmp, b.small, s);
+    launch_rescale01(b.small, k, (size_t)b.h * b.w, b.mn, b.mx, b.x, s);
+    float *mn = (float *)c->scratch, *mx = mn + k;
+    launch_minmax_f32(b.x, k, (size_t)b.h * b.w, mn, mx, s);
+    launch_extract_tiles(b.x, mn, k, g, c->patch_in, s);
+    int rc = unet_down_dev(c, c->patch_in, k * g.tiles_per_img, c->dout[slot], s);
+    if (rc) return rc;
+    TMAT_HIP(hipEventRecord(c->ev_down[slot], s));
+    return TMAT_OK;
+}
+static int enqueue_back(Ctx *c, int k, int slot, const TileGeom &g)
+{
+    PassBuf &b = c->pass;
+    hipStream_t s = c->stream;
+    TMAT_HIP(hipStreamWaitEvent(s, c->ev_down[slot], 0));
+    int rc = unet_up_dev(c, c->dout[slot], k * g.tiles_per_img, c->patch_out, s);
+    if (rc) return rc;
+    launch_blend(c->patch_out, c->win1d, k, g, b.pred[slot], s);
+    TMAT_HIP(hipMemcpyAsync(b.pred_host[slot], b.pred[slot], (size_t)k * b.h * b.w * sizeof(double), hipMemcpyDeviceToHost, s));
+    TMAT_HIP(hipEventRecord(b.done[slot], s));
+    return TMAT_OK;
+}
+
 struct GraphParams {
     int fh, fw;
     float t1, t2;
@@ -151,7 +181,10 @@ static int analyze_dev(Ctx *c, const uint16_t *imgs_dev, int n, int H, int W, do
     const int P = (n + K - 1) / K;
     HostJob jobs[2];
     auto cnt = [&](int p) { return std::min(K, n - p * K); };
-    rc = enqueue_segment(c, imgs_dev, cnt(0), 0);
+    auto img_at = [&](int p) { return imgs_dev + (size_t)p * K * H * W; };
+    rc = enqueue_front(c, img_at(0), cnt(0), 0, g);
+    if (!rc) rc = enqueue_back(c, cnt(0), 0, g);
+    if (!rc && P > 1) rc = enqueue_front(c, img_at(1), cnt(1), 1, g);
     for (int p = 0; p < P && !rc; p++) {
         const int slot = p & 1;
         const double tw0 = now_s();
@@ -161,10 +194,12 @@ static int analyze_dev(Ctx *c, const uint16_t *imgs_dev, int n, int H, int W, do
         if (trace_on())
             fprintf(stderr, "[tmat] pass %d/%d (%d images): waited %.1f ms for the GPU, %.1f ms for host jobs of the previous pass\n",
                     p + 1, P, cnt(p), (tw1 - tw0) * 1e3, (now_s() - tw1) * 1e3);
-        if (p + 1 < P && !rc) rc = enqueue_segment(c, imgs_dev + (size_t)(p + 1) * K * H * W, cnt(p + 1), slot ^ 1);
+        if (p + 1 < P && !rc) rc = enqueue_back(c, cnt(p + 1), slot ^ 1, g);
+        if (p + 2 < P && !rc) rc = enqueue_front(c, img_at(p + 2), cnt(p + 2), slot, g);
         if (!rc) start_host_job(jobs[slot], c->pass.pred_host[slot], cnt(p), h, w, gp, rows + (size_t)p * K);
     }
     for (auto &j : jobs) { j.join(); if (j.rc && !rc) rc = j.rc; }
+    hipStreamSynchronize(c->stream2);
     hipStreamSynchronize(c->stream);
     return rc;
 }

@@ -155,86 +155,103 @@ static bool build_model(Ctx *c, const std::map<std::string, Tensor> &m)
 // UNet forward on device patches X (n, P, P) -> Y (n, P, P); n <= max_patches.
 // Buffer plan (4 ping-pong activation buffers) is documented in DESIGN.md.
 // ---------------------------------------------------------------------------------------------
-static void prof_begin(Ctx *c, double flops)
+static void prof_begin(Ctx *c, double flops, hipStream_t st)
 {
     if (!c->prof_on) return;
     hipEvent_t e0, e1;
     if (c->ev_pool.size() >= 2) { e0 = c->ev_pool.back(); c->ev_pool.pop_back(); e1 = c->ev_pool.back(); c->ev_pool.pop_back(); }
     else { hipEventCreate(&e0); hipEventCreate(&e1); }
-    hipEventRecord(e0, c->stream);
+    hipEventRecord(e0, st);
     c->ev_open.push_back({e0, e1, flops});
 }
-static void prof_end(Ctx *c)
+static void prof_end(Ctx *c, hipStream_t st)
 {
     if (!c->prof_on) return;
-    hipEventRecord(c->ev_open.back().e1, c->stream);
+    hipEventRecord(c->ev_open.back().e1, st);
 }
 
-static bool conv(Ctx *c, ConvArgs a)
+static bool conv(Ctx *c, ConvArgs a, hipStream_t st)
 {
     bool dom = a.ksize == 3;
     if (dom) {
         double H = (double)(a.h << a.up), W = (double)(a.w << a.up);
-        prof_begin(c, 2.0 * a.N * H * W * 9.0 * a.Cin * a.Cout);
+        prof_begin(c, 2.0 * a.N * H * W * 9.0 * a.Cin * a.Cout, st);
     }
-    bool ok = launch_conv(a, c->stream);
-    if (dom) prof_end(c);
+    bool ok = launch_conv(a, st);
+    if (dom) prof_end(c, st);
     return ok;
 }
 
-int unet_forward_dev(Ctx *c, const float *X, int n, float *Y)
+// Down path (memory-bound kernels + small pointwise GEMMs): X (n, P, P) -> dout (n, P/16, P/16, f_deep)
+int unet_down_dev(Ctx *c, const float *X, int n, float *dout, hipStream_t s)
 {
     if (n <= 0) return TMAT_OK;
-    if (n > c->max_patches) { set_error("unet_forward_dev: n > max_patches"); return TMAT_E_ARG; }
-    hipStream_t s = c->stream;
+    if (n > c->max_patches) { set_error("unet_down_dev: n > max_patches"); return TMAT_E_ARG; }
     const int P = c->patch;
     float *b0 = c->buf[0], *b1 = c->buf[1], *b2 = c->buf[2], *b3 = c->buf[3];
     launch_stem(X, n, P, P, c->stem_w, c->f0, c->stem_scale, c->stem_shift, b0, s);
     int H = P / 2;
-    for (auto &d : c->down) {
+    for (size_t bi = 0; bi < c->down.size(); bi++) {
+        auto &d = c->down[bi];
         // prev = b0 (n, H, H, cin)
         launch_dwconv(b0, n, H, H, d.cin, 1, d.dw[0], b1, s);
         ConvArgs a{};
         a.in = b1; a.N = n; a.h = H; a.w = H; a.Cin = d.cin; a.up = 0; a.relu_in = 0; a.ksize = 1; a.stride = 1;
         a.W = d.pw[0]; a.Cout = d.cout; a.scale = d.scale[0]; a.shift = d.shift[0]; a.resid = nullptr; a.rs = 0;
         a.relu_out = 1; a.out = b2;
-        if (!conv(c, a)) return TMAT_E_ARG;
+        if (!conv(c, a, s)) return TMAT_E_ARG;
         launch_dwconv(b2, n, H, H, d.cout, 0, d.dw[1], b3, s);
         a.in = b3; a.Cin = d.cout; a.W = d.pw[1]; a.scale = d.scale[1]; a.shift = d.shift[1]; a.relu_out = 0; a.out = b2;
-        if (!conv(c, a)) return TMAT_E_ARG;
+        if (!conv(c, a, s)) return TMAT_E_ARG;
         ConvArgs r{};
         r.in = b0; r.N = n; r.h = H; r.w = H; r.Cin = d.cin; r.ksize = 1; r.stride = 2; r.W = d.res_w; r.Cout = d.cout;
         r.scale = nullptr; r.shift = d.res_b; r.out = b1;
-        if (!conv(c, r)) return TMAT_E_ARG;
-        launch_maxpool_add(b2, n, H, H, d.cout, b1, b0, s);
+        if (!conv(c, r, s)) return TMAT_E_ARG;
+        launch_maxpool_add(b2, n, H, H, d.cout, b1, bi + 1 == c->down.size() ? dout : b0, s);
         H /= 2;
     }
-    // up path: S = stored tensor at resolution Hs; logical block input = Up^up(S)
-    float *S = b0;
-    int Hs = H, up = 0;
-    float *free3[3] = {b1, b2, b3};
+    TMAT_HIP(hipGetLastError());
+    return TMAT_OK;
+}
+
+// Up path (the MFMA-bound 3x3 transposed convolutions) + final conv: dout -> Y (n, P, P)
+int unet_up_dev(Ctx *c, const float *dout, int n, float *Y, hipStream_t s)
+{
+    if (n <= 0) return TMAT_OK;
+    // S = stored tensor at resolution Hs; logical block input = Up^up(S).  `dout` is never recycled.
+    const float *S = dout;
+    int Hs = c->patch >> (1 + c->down.size()), up = 0;
+    float *t1 = c->ubuf[0], *rr = c->ubuf[1];
+    int so_idx = 2;
     for (auto &u : c->up) {
-        float *t1 = free3[0], *rr = free3[1], *so = free3[2];
+        float *so = c->ubuf[so_idx];
         ConvArgs a{};
         a.in = S; a.N = n; a.h = Hs; a.w = Hs; a.Cin = u.cin; a.up = up; a.relu_in = 1; a.ksize = 3; a.stride = 1;
         a.W = u.ct[0]; a.Cout = u.cout; a.scale = u.scale[0]; a.shift = u.shift[0]; a.relu_out = 1; a.out = t1;
-        if (!conv(c, a)) return TMAT_E_ARG;
+        if (!conv(c, a, s)) return TMAT_E_ARG;
         ConvArgs r{};
         r.in = S; r.N = n; r.h = Hs; r.w = Hs; r.Cin = u.cin; r.ksize = 1; r.stride = 1; r.W = u.res_w; r.Cout = u.cout;
         r.scale = nullptr; r.shift = u.res_b; r.out = rr;
-        if (!conv(c, r)) return TMAT_E_ARG;
+        if (!conv(c, r, s)) return TMAT_E_ARG;
         const int Hl = Hs << up;
         ConvArgs b{};
         b.in = t1; b.N = n; b.h = Hl; b.w = Hl; b.Cin = u.cout; b.up = 0; b.relu_in = 0; b.ksize = 3; b.stride = 1;
         b.W = u.ct[1]; b.Cout = u.cout; b.scale = u.scale[1]; b.shift = u.shift[1]; b.resid = rr; b.rs = up; b.relu_out = 0;
         b.out = so;
-        if (!conv(c, b)) return TMAT_E_ARG;
-        free3[2] = S; S = so;      // old S becomes free
+        if (!conv(c, b, s)) return TMAT_E_ARG;
+        S = so; so_idx = so_idx == 2 ? 3 : 2;
         Hs = Hl; up = 1;
     }
     launch_final(S, n, Hs, Hs, c->f_last, c->final_w, c->final_b, Y, s);
     TMAT_HIP(hipGetLastError());
     return TMAT_OK;
+}
+
+int unet_forward_dev(Ctx *c, const float *X, int n, float *Y)
+{
+    int rc = unet_down_dev(c, X, n, c->dout[0], c->stream);
+    if (rc) return rc;
+    return unet_up_dev(c, c->dout[0], n, Y, c->stream);
 }
 
 // predict_img_with_smooth_windowing on device: x_dev (n, hh, ww) f32 -> pred_dev (n, hh, ww) f64
@@ -296,6 +313,20 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
             tmat_destroy((tmat_handle)c); return TMAT_E_HIP;
         }
     }
+    // up-path buffers: t1 (unit), hoisted residual (unit/4), block outputs alternate (unit/2, unit); down-path output x2
+    const size_t usizes[4] = {unit, unit / 4, unit / 2, unit};
+    for (int i = 0; i < 4; i++)
+        if (!hip_ok(hipMalloc((void **)&c->ubuf[i], usizes[i] * c->max_patches * sizeof(float)), "hipMalloc(up buffers)")) {
+            tmat_destroy((tmat_handle)c); return TMAT_E_HIP;
+        }
+    const size_t dsz = (size_t)(patch >> (1 + c->down.size())) * (patch >> (1 + c->down.size())) * c->up[0].cin;
+    for (int i = 0; i < 2; i++)
+        if (!hip_ok(hipMalloc((void **)&c->dout[i], dsz * c->max_patches * sizeof(float)), "hipMalloc(dout)")) {
+            tmat_destroy((tmat_handle)c); return TMAT_E_HIP;
+        }
+    if (!hip_ok(hipStreamCreate(&c->stream2), "hipStreamCreate(2)")) { tmat_destroy((tmat_handle)c); return TMAT_E_HIP; }
+    for (int i = 0; i < 2; i++)
+        if (!hip_ok(hipEventCreateWithFlags(&c->ev_down[i], hipEventDisableTiming), "hipEventCreate")) { tmat_destroy((tmat_handle)c); return TMAT_E_HIP; }
     const size_t pp = (size_t)patch * patch * c->max_patches * sizeof(float);
     c->scratch_bytes = 64 << 20;
     if (!hip_ok(hipMalloc((void **)&c->patch_in, pp), "hipMalloc(patch_in)") ||
@@ -338,7 +369,11 @@ void tmat_destroy(tmat_handle h)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (void *p : c->owned) hipFree(p);
+    if (c->stream2) hipStreamSynchronize(c->stream2);
     for (int i = 0; i < 4; i++) if (c->buf[i]) hipFree(c->buf[i]);
+    for (int i = 0; i < 4; i++) if (c->ubuf[i]) hipFree(c->ubuf[i]);
+    for (int i = 0; i < 2; i++) { if (c->dout[i]) hipFree(c->dout[i]); if (c->ev_down[i]) hipEventDestroy(c->ev_down[i]); }
+    if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->patch_in) hipFree(c->patch_in);
     if (c->patch_out) hipFree(c->patch_out);
     if (c->scratch) hipFree(c->scratch);
@@ -354,6 +389,7 @@ int tmat_sync(tmat_handle h)
 {
     Ctx *c = (Ctx *)h;
     if (!c) { set_error("null handle"); return TMAT_E_ARG; }
+    if (c->stream2) TMAT_HIP(hipStreamSynchronize(c->stream2));
     TMAT_HIP(hipStreamSynchronize(c->stream));
     return TMAT_OK;
 }

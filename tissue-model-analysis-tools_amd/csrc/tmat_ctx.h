@@ -45,7 +45,11 @@ struct Ctx {
     float *final_w = nullptr;
     float final_b = 0.f;
     std::vector<void *> owned;              // weight allocations
-    float *buf[4] = {nullptr, nullptr, nullptr, nullptr};
+    float *buf[4] = {nullptr, nullptr, nullptr, nullptr};    // down-path ping-pong activations
+    float *ubuf[4] = {nullptr, nullptr, nullptr, nullptr};   // up-path activations
+    float *dout[2] = {nullptr, nullptr};                     // down-path output (P/16)^2 x f_deep, double-buffered
+    hipStream_t stream2 = nullptr;                           // second stream: down path of pass p+1 overlaps up path of pass p
+    hipEvent_t ev_down[2] = {nullptr, nullptr};
     float *patch_in = nullptr, *patch_out = nullptr;
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -72,6 +76,8 @@ struct Ctx {
 };
 
 int unet_forward_dev(Ctx *c, const float *X, int n, float *Y);
+int unet_down_dev(Ctx *c, const float *X, int n, float *dout, hipStream_t s);
+int unet_up_dev(Ctx *c, const float *dout, int n, float *Y, hipStream_t s);
 int predict_smooth_dev(Ctx *c, const float *x_dev, int n, int hh, int ww, double *pred_dev);
 
 // numpy's pairwise summation of a contiguous f64 vector (np.add.reduce / np.mean inner loop):
