@@ -135,21 +135,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int M, int H
     {                                                                                  \
         const float *Ab = &As[buf_][aoff];                                             \
         const float *Bb = &Bs[buf_][boff];                                             \
-        float av[2][TM], bv[2][TN];                                                    \
-        _Pragma("unroll") for (int i = 0; i < TM; i++) av[0][i] = Ab[i * 32];          \
-        _Pragma("unroll") for (int jn = 0; jn < TN; jn++) bv[0][jn] = Bb[jn * 32];     \
         _Pragma("unroll") for (int kk = 0; kk < KC / 2; kk++) {                        \
-            const int cur = kk & 1, nx = cur ^ 1;                                      \
-            if (kk + 1 < KC / 2) {                                                     \
-                _Pragma("unroll") for (int i = 0; i < TM; i++) av[nx][i] = Ab[(kk + 1) * 2 * LDA + i * 32];   \
-                _Pragma("unroll") for (int jn = 0; jn < TN; jn++) bv[nx][jn] = Bb[(kk + 1) * 2 * BN + jn * 32]; \
-            }                                                                          \
+            float av[TM], bv[TN];                                                      \
+            _Pragma("unroll") for (int i = 0; i < TM; i++) av[i] = Ab[kk * 2 * LDA + i * 32];   \
+            _Pragma("unroll") for (int jn = 0; jn < TN; jn++) bv[jn] = Bb[kk * 2 * BN + jn * 32]; \
             _Pragma("unroll") for (int i = 0; i < TM; i++)                             \
                 _Pragma("unroll") for (int jn = 0; jn < TN; jn++)                      \
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][jn], acc[i][jn], 0, 0, 0); \
-            /* issue order: the LDS reads of k-pair kk+1, then the MFMAs of k-pair kk */ \
-            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);                   \
-            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);                   \
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[jn], acc[i][jn], 0, 0, 0); \
         }                                                                              \
     }
 
