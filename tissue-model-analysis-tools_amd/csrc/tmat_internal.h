@@ -27,6 +27,8 @@ struct ConvArgs {
     int rs;
     int relu_out;
     float *out;           // (N, H/stride, W/stride, Cout), H = h << up
+    const float *zeros;   // >= Cin zero floats: source of out-of-image taps (set by launch_conv)
+    int stagger;          // start delay (x 512 cycles) of every second generation of blocks (set by launch_conv)
 };
 // returns false (and sets the error) on unsupported shapes
 bool launch_conv(const ConvArgs &a, hipStream_t s);

@@ -12,6 +12,8 @@
 #include "tmat_internal.h"
 #include "../../include/tmat.h"
 
+#include <cstdlib>
+
 namespace tmat {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -25,7 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   Register-prefetch double buffering: one barrier per K chunk.
 // ---------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int KC>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int M, int Ho, int Wo, int nMt, int nNt)
+__global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_mfma_kernel(ConvArgs a, int M, int Ho, int Wo, int nMt, int nNt)
 {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -50,6 +52,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int M, int H
     // XCD-aware tile mapping: blocks b and b+8 share an XCD (round-robin dispatch); give the
     // nNt column tiles of one pixel tile to the same XCD so its L2 serves the re-read A pixels.
     const int b = blockIdx.x;
+    // Co-resident blocks of one CU (2 per CU here) are dispatched together and would run in lockstep: both in their
+    // staging / barrier phase at the same time, both competing for the MFMA pipe at the same time.  Delaying every
+    // second generation of 256 blocks by about half a K-chunk period keeps the pairs out of phase for the whole launch.
+    if ((b >> 8) & 1)
+        for (int i = 0; i < (a.stagger & 255); i++) __builtin_amdgcn_s_sleep(8);
     const int xcd = b & 7, j = b >> 3;
     const int nt = j % nNt;
     const int mt = (j / nNt) * 8 + xcd;
@@ -87,48 +94,67 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int M, int H
     // registers are written to LDS), so the next chunk's global loads stay in flight across the MFMA loop.
     // Two register sets (P, Q) hold the chunks c+1 and c+2 while chunk c is multiplied: a chunk's global loads
     // have two MFMA phases (~8k cycles) to land before they are written to LDS.
+    // Loader state machine (chunks are loaded strictly in order): per staged pixel a base pointer for the current
+    // tap -- the input pixel, or a zero row for out-of-image taps, so the loads are unconditional and need no
+    // select afterwards -- recomputed only when the tap changes; the weight pointer just advances by KC rows
+    // (W is [tap][Cin][Cout], i.e. chunk after chunk is contiguous).
     float4 pa0, pa1, pa2, pa3, pa4, pa5, pa6, pa7, pb0, pb1, pb2, pb3;
     float4 qa0, qa1, qa2, qa3, qa4, qa5, qa6, qa7, qb0, qb1, qb2, qb3;
-    bool pk0 = false, pk1 = false, pk2 = false, pk3 = false, pk4 = false, pk5 = false, pk6 = false, pk7 = false;
-    bool qk0 = false, qk1 = false, qk2 = false, qk3 = false, qk4 = false, qk5 = false, qk6 = false, qk7 = false;
     static_assert(NPA == 4 || NPA == 8 || NPA == 2, "A passes");
     static_assert(NPB == 4 || NPB == 2 || NPB == 1, "B passes");
-    const float relu_lo = a.relu_in ? 0.f : -INFINITY;      // relu on load folded into one max
+    const float *ab0 = a.zeros, *ab1 = a.zeros, *ab2 = a.zeros, *ab3 = a.zeros, *ab4 = a.zeros, *ab5 = a.zeros, *ab6 = a.zeros,
+                *ab7 = a.zeros;
+    const float *wp = a.W + n0 + bcol + (size_t)brow * a.Cout;
+    int ld_tap = 0, ld_c0 = 0, ld_cc = 0;
 
-#define TMAT_LOAD_A(i, R, OK)                                                                               \
+#define TMAT_BASE(i, AB)                                                                                    \
     if (i < NPA) {                                                                                          \
         const int yy = py[i] + dy, xx = px[i] + dx;                                                         \
-        OK = pok[i] && yy >= 0 && yy < H && xx >= 0 && xx < W;                                              \
-        const size_t off = OK ? ((size_t)(pbase[i] + (yy >> a.up)) * a.w + (xx >> a.up)) * a.Cin : (size_t)0; \
-        R = *reinterpret_cast<const float4 *>(a.in + off + c0 + c4);                                        \
+        const bool ok = pok[i] && yy >= 0 && yy < H && xx >= 0 && xx < W;                                   \
+        AB = ok ? a.in + ((size_t)(pbase[i] + (yy >> a.up)) * a.w + (xx >> a.up)) * a.Cin + c4 : a.zeros + c4; \
     }
-#define TMAT_LOAD_B(i, R) \
-    if (i < NPB) R = *reinterpret_cast<const float4 *>(wp + (size_t)(i * RPP + brow) * a.Cout);
-#define TMAT_LOAD_CHUNK(cc_, S)                                                        \
+#define TMAT_LOAD_CHUNK(S)                                                             \
     {                                                                                  \
-        const int cc = (cc_) < nchunks ? (cc_) : nchunks - 1;                          \
-        const int tap = cc / cchunks;                                                  \
-        const int c0 = (cc - tap * cchunks) * KC;                                      \
-        const int dy = a.ksize == 3 ? tap / 3 - 1 : 0;                                 \
-        const int dx = a.ksize == 3 ? tap % 3 - 1 : 0;                                 \
-        TMAT_LOAD_A(0, S##a0, S##k0) TMAT_LOAD_A(1, S##a1, S##k1) TMAT_LOAD_A(2, S##a2, S##k2) TMAT_LOAD_A(3, S##a3, S##k3) \
-        TMAT_LOAD_A(4, S##a4, S##k4) TMAT_LOAD_A(5, S##a5, S##k5) TMAT_LOAD_A(6, S##a6, S##k6) TMAT_LOAD_A(7, S##a7, S##k7) \
-        const float *wp = a.W + ((size_t)tap * a.Cin + c0) * a.Cout + n0 + bcol;       \
-        TMAT_LOAD_B(0, S##b0) TMAT_LOAD_B(1, S##b1) TMAT_LOAD_B(2, S##b2) TMAT_LOAD_B(3, S##b3) \
+        if (ld_c0 == 0) {                                                              \
+            const int dy = a.ksize == 3 ? ld_tap / 3 - 1 : 0;                          \
+            const int dx = a.ksize == 3 ? ld_tap % 3 - 1 : 0;                          \
+            TMAT_BASE(0, ab0) TMAT_BASE(1, ab1) TMAT_BASE(2, ab2) TMAT_BASE(3, ab3)    \
+            TMAT_BASE(4, ab4) TMAT_BASE(5, ab5) TMAT_BASE(6, ab6) TMAT_BASE(7, ab7)    \
+        }                                                                              \
+        if (0 < NPA) S##a0 = *reinterpret_cast<const float4 *>(ab0 + ld_c0);           \
+        if (1 < NPA) S##a1 = *reinterpret_cast<const float4 *>(ab1 + ld_c0);           \
+        if (2 < NPA) S##a2 = *reinterpret_cast<const float4 *>(ab2 + ld_c0);           \
+        if (3 < NPA) S##a3 = *reinterpret_cast<const float4 *>(ab3 + ld_c0);           \
+        if (4 < NPA) S##a4 = *reinterpret_cast<const float4 *>(ab4 + ld_c0);           \
+        if (5 < NPA) S##a5 = *reinterpret_cast<const float4 *>(ab5 + ld_c0);           \
+        if (6 < NPA) S##a6 = *reinterpret_cast<const float4 *>(ab6 + ld_c0);           \
+        if (7 < NPA) S##a7 = *reinterpret_cast<const float4 *>(ab7 + ld_c0);           \
+        if (0 < NPB) S##b0 = *reinterpret_cast<const float4 *>(wp);                    \
+        if (1 < NPB) S##b1 = *reinterpret_cast<const float4 *>(wp + (size_t)(1 * RPP) * a.Cout); \
+        if (2 < NPB) S##b2 = *reinterpret_cast<const float4 *>(wp + (size_t)(2 * RPP) * a.Cout); \
+        if (3 < NPB) S##b3 = *reinterpret_cast<const float4 *>(wp + (size_t)(3 * RPP) * a.Cout); \
+        /* the loads are issued unconditionally (a guard would force the compiler to drain the prefetch at every   \
+           LDS store); past the last chunk the state simply stops advancing and the last chunk is re-read, unused */ \
+        ld_cc++;                                                                       \
+        if (ld_cc < nchunks) {                                                         \
+            wp += (size_t)KC * a.Cout;                                                 \
+            ld_c0 += KC;                                                               \
+            if (ld_c0 == a.Cin) { ld_c0 = 0; ld_tap++; }                               \
+        }                                                                              \
     }
-#define TMAT_STORE_A(i, R, OK)                                                         \
+#define TMAT_STORE_A(i, R)                                                             \
     if (i < NPA) {                                                                     \
         float *d = &As[bb][c4 * LDA + i * PPP + t / TPP];                              \
-        d[0] = OK ? fmaxf(R.x, relu_lo) : 0.f; d[LDA] = OK ? fmaxf(R.y, relu_lo) : 0.f; \
-        d[2 * LDA] = OK ? fmaxf(R.z, relu_lo) : 0.f; d[3 * LDA] = OK ? fmaxf(R.w, relu_lo) : 0.f; \
+        if (a.relu_in) { d[0] = fmaxf(R.x, 0.f); d[LDA] = fmaxf(R.y, 0.f); d[2 * LDA] = fmaxf(R.z, 0.f); d[3 * LDA] = fmaxf(R.w, 0.f); } \
+        else { d[0] = R.x; d[LDA] = R.y; d[2 * LDA] = R.z; d[3 * LDA] = R.w; }         \
     }
 #define TMAT_STORE_B(i, R) \
     if (i < NPB) *reinterpret_cast<float4 *>(&Bs[bb][(i * RPP + brow) * BN + bcol]) = R;
 #define TMAT_STORE_CHUNK(buf_, S)                                                      \
     {                                                                                  \
         const int bb = (buf_);                                                         \
-        TMAT_STORE_A(0, S##a0, S##k0) TMAT_STORE_A(1, S##a1, S##k1) TMAT_STORE_A(2, S##a2, S##k2) TMAT_STORE_A(3, S##a3, S##k3) \
-        TMAT_STORE_A(4, S##a4, S##k4) TMAT_STORE_A(5, S##a5, S##k5) TMAT_STORE_A(6, S##a6, S##k6) TMAT_STORE_A(7, S##a7, S##k7) \
+        TMAT_STORE_A(0, S##a0) TMAT_STORE_A(1, S##a1) TMAT_STORE_A(2, S##a2) TMAT_STORE_A(3, S##a3) \
+        TMAT_STORE_A(4, S##a4) TMAT_STORE_A(5, S##a5) TMAT_STORE_A(6, S##a6) TMAT_STORE_A(7, S##a7) \
         TMAT_STORE_B(0, S##b0) TMAT_STORE_B(1, S##b1) TMAT_STORE_B(2, S##b2) TMAT_STORE_B(3, S##b3) \
     }
 #define TMAT_MFMA_CHUNK(buf_)                                                          \
@@ -156,28 +182,27 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a, int M, int H
     const int aoff = (lane >> 5) * LDA + wm * (BM / WM) + (lane & 31);
     const int boff = (lane >> 5) * BN + wn * (BN / WN) + (lane & 31);
 
-    TMAT_LOAD_CHUNK(0, p)
+    TMAT_LOAD_CHUNK(p)
     TMAT_STORE_CHUNK(0, p)
-    TMAT_LOAD_CHUNK(1, q)
+    TMAT_LOAD_CHUNK(q)
     __syncthreads();
 
     // chunk c lives in LDS buffer c & 1; register set p carries even chunks, q odd ones (nchunks is even: host check)
     for (int c = 0; c < nchunks; c += 2) {
-        TMAT_LOAD_CHUNK(c + 2, p)
+        TMAT_LOAD_CHUNK(p)
         __builtin_amdgcn_sched_barrier(0);      // keep the staging math of prefetched chunks out of the MFMA loop
         TMAT_MFMA_CHUNK(0)
         __builtin_amdgcn_sched_barrier(0);
         TMAT_STORE_CHUNK(1, q)                  // chunk c + 1
         __syncthreads();
-        TMAT_LOAD_CHUNK(c + 3, q)
+        TMAT_LOAD_CHUNK(q)
         __builtin_amdgcn_sched_barrier(0);
         TMAT_MFMA_CHUNK(1)
         __builtin_amdgcn_sched_barrier(0);
         TMAT_STORE_CHUNK(0, p)                  // chunk c + 2
         __syncthreads();
     }
-#undef TMAT_LOAD_A
-#undef TMAT_LOAD_B
+#undef TMAT_BASE
 #undef TMAT_LOAD_CHUNK
 #undef TMAT_STORE_A
 #undef TMAT_STORE_B
@@ -258,10 +283,22 @@ bool launch_conv(const ConvArgs &a, hipStream_t s)
         return false;
     }
     const int M = (int)Mll;
+    static const int stagger = [] { const char *e = getenv("TMAT_STAGGER"); return e ? atoi(e) : 0; }();
+    static float *zeros = nullptr;        // 2048 zero floats shared by every launch (out-of-image taps read it)
+    if (!zeros) {
+        if (hipMalloc((void **)&zeros, 2048 * sizeof(float)) != hipSuccess || hipMemset(zeros, 0, 2048 * sizeof(float)) != hipSuccess) {
+            set_error("launch_conv: cannot allocate the zero row");
+            return false;
+        }
+    }
+    if (a.Cin > 2048) { set_error("launch_conv: Cin > 2048"); return false; }
+    ConvArgs b = a;
+    b.stagger = stagger;
+    b.zeros = zeros;
     if (a.Cout % 128 == 0)
-        launch_conv_cfg<128, 128, 2, 2, 32>(a, M, Ho, Wo, s);
+        launch_conv_cfg<128, 128, 2, 2, 32>(b, M, Ho, Wo, s);
     else
-        launch_conv_cfg<256, 64, 4, 1, 16>(a, M, Ho, Wo, s);
+        launch_conv_cfg<256, 64, 4, 1, 16>(b, M, Ho, Wo, s);
     return true;
 }
 
