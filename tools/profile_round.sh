@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round profile bundle (run on the GPU box through gpurun): default bench line, rocprofv3 --kernel-trace --stats of
+# the same command, and separate PMC passes (FETCH_SIZE / WRITE_SIZE / MFMA busy) on a short run of the same pipeline.
+# Usage: bash tools/profile_round.sh r01
+set -e
+R=${1:-r01}
+ROOT=$GRAFT_REPO_ROOT
+OUT=$ROOT/gpurun_out/profiles_$R
+mkdir -p $OUT
+cd $ROOT
+python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+tail -1 $OUT/bench.json | cut -c1-300
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
+rm -rf $OUT/trace            # the raw per-dispatch trace is large; the stats summary is what is kept
+echo "kernel-trace done"
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
+  tag=$(echo $grp | cut -d' ' -f1)
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_$tag -- python3 $ROOT/bench.py --images 16 --distinct 4 --no-cpu-baseline > $OUT/pmc_$tag.json 2> $OUT/pmc_$tag.err || echo "pmc $tag failed"
+  find $OUT/pmc_$tag -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} $OUT/pmc_$tag.csv || true
+  find $OUT/pmc_$tag -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} $OUT/pmc_${tag}_trace.csv || true
+  rm -rf $OUT/pmc_$tag
+  echo "pmc $tag done"
+done
+ls -la $OUT
