@@ -78,6 +78,14 @@ int tmat_segment_batch(tmat_handle h, const uint16_t *imgs, int n, int H, int W,
 int tmat_postprocess_batch(tmat_handle h, const double *pred, int n, int hh, int ww, int out_h, int out_w, float *field);
 
 /*
+ * The GPU part of the above (csrc/morph_kernels.hip): pred > 0.5 -> filter_branch_seg_mask
+ * (transforms.py:306-361, remove_isolated=True) -> EDT of the filtered mask (the `distance` output of
+ * medial_axis(seg_mask, return_distance=True), compute_branches.py:340).
+ * pred (n, h, w) f64; filtered (n, h, w) u8; dist (n, h, w) f64.  Needs a handle (runs on its device).
+ */
+int tmat_filter_edt_batch(tmat_handle h, const double *pred, int n, int hh, int ww, uint8_t *filtered, double *dist);
+
+/*
  * fl_tissue_model_tools.dmtgraph.compute_dmt_graph(img, delta1, delta2) (reference
  * dmtgraph.py:38-99; the contract the un-vendored pydmtgraph C++ extension exposed).
  * img: (rows, cols) f32.  verts: (cap_v, 2) int32 [row, col]; edges: (cap_e, 2) int32.
@@ -152,8 +160,9 @@ int tmat_host_postprocess(const double *pred, int H, int W, int out_h, int out_w
 
 /*
  * Timing hook for bench.py's roofline line: accumulated HIP-event time (ms) and launch count of
- * the dominant kernel family (3x3 implicit-GEMM MFMA convolutions) since the last reset, measured
- * on the handle's own stream.  flops = algorithmic FLOPs of those launches.
+ * the dominant kernel -- tmat::conv_mfma_kernel<128, 128, 2, 2, 32, 3>, the 3x3 implicit-GEMM MFMA
+ * convolution instantiation that runs 6 of the 8 transposed-conv layers -- since the last reset, measured
+ * on the stream it is launched on.  flops = algorithmic FLOPs of those launches.
  */
 int tmat_prof_enable(tmat_handle h, int on);
 int tmat_prof_read(tmat_handle h, double *ms, int64_t *launches, double *flops, int reset);

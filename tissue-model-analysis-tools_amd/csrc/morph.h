@@ -1,0 +1,13 @@
+// GPU binary morphology (morph_kernels.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+namespace tmat {
+size_t morph_workspace_bytes(int k, int H, int W);
+// device pointer to the k per-image "thinning converged" flags inside the workspace (1 = converged)
+const int *morph_done_flags(void *workspace, int k, int H, int W);
+// pred (k, H, W) f64 device -> filtered mask (k, H, W) u8 device, EDT of it (k, H, W) f64 device; all async on `s`
+int filter_edt_dev(const double *pred, int k, int H, int W, int remove_isolated, void *workspace, uint8_t *filt_out,
+                   double *dist_out, hipStream_t s);
+}  // namespace tmat

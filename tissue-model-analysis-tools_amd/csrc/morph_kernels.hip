@@ -1,0 +1,323 @@
+// Binary morphology of the segmentation mask on gfx950 (batch of images, one launch per step):
+//   a11  seg = pred > 0.5                                              compute_branches.py:334
+//   a12  filter_branch_seg_mask (transforms.py:306-361):
+//        13-tap binary median (disk(2), 'nearest') -> 8-connected labelling (union-find, root = smallest pixel
+//        index) -> area / 4-neighbourhood perimeter codes per label -> circularity -> Zhang thinning with
+//        scikit-image's table (two parallel sub-iterations to convergence) -> skeleton components + fork test ->
+//        drop components without a fork or with circularity > 0.8
+//   a14a exact EDT of the filtered mask (Meijster, integer squared distances -> sqrt in f64), the `distance`
+//        of medial_axis (compute_branches.py:340); the ordered thinning itself is sequential and stays on the host.
+// All of it is integer / byte work: HBM-bound streaming kernels plus atomics on per-label counters.
+// Results are identical to csrc/postproc.cpp (host twin used by the stage-wise C-ABI entry points) and to
+// oracle/morph.py: the label ids differ (root pixel index instead of raster rank) but no output depends on them.
+#include "tmat_internal.h"
+#include "morph.h"
+
+namespace tmat {
+
+#include "skel_lut.inc"
+__constant__ unsigned char d_skel_lut[256];
+
+static bool g_lut_uploaded = false;
+static bool upload_lut()
+{
+    if (g_lut_uploaded) return true;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(d_skel_lut), SKEL_LUT, 256) != hipSuccess) return false;
+    g_lut_uploaded = true;
+    return true;
+}
+
+#define IMG_LOOP(p, n_px) for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < (n_px); p += gridDim.x * blockDim.x)
+
+__global__ void threshold_kernel(const double *__restrict__ pred, uint8_t *__restrict__ seg, int npx)
+{
+    const size_t base = (size_t)blockIdx.y * npx;
+    IMG_LOOP(p, npx) seg[base + p] = pred[base + p] > 0.5;
+}
+
+__global__ void median13_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int H, int W)
+{
+    const size_t base = (size_t)blockIdx.y * H * W;
+    IMG_LOOP(p, H * W) {
+        const int y = p / W, x = p - y * W;
+        int c = 0;
+#pragma unroll
+        for (int dy = -2; dy <= 2; dy++) {
+            const int r = 2 - (dy < 0 ? -dy : dy);
+            const int yy = min(max(y + dy, 0), H - 1);
+            for (int dx = -r; dx <= r; dx++) c += in[base + (size_t)yy * W + min(max(x + dx, 0), W - 1)];
+        }
+        out[base + p] = c >= 7;
+    }
+}
+
+// ---- 8-connected labelling: union-find with atomicMin, root = smallest pixel index of the component ----
+__device__ __forceinline__ int uf_find(const int *L, int x)
+{
+    for (;;) {
+        const int p = __hip_atomic_load(&L[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == x) return x;
+        x = p;
+    }
+}
+__device__ __forceinline__ void uf_union(int *L, int a, int b)
+{
+    for (;;) {
+        a = uf_find(L, a); b = uf_find(L, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = atomicMin(&L[a], b);      // a > b: hang root a under b
+        if (old == a) return;
+        a = old;
+    }
+}
+__global__ void ccl_init_kernel(const uint8_t *__restrict__ m, int *__restrict__ L, int npx)
+{
+    const size_t base = (size_t)blockIdx.y * npx;
+    IMG_LOOP(p, npx) L[base + p] = m[base + p] ? p : -1;
+}
+__global__ void ccl_merge_kernel(const uint8_t *__restrict__ m, int *__restrict__ L, int H, int W)
+{
+    const size_t base = (size_t)blockIdx.y * H * W;
+    const uint8_t *mm = m + base;
+    int *LL = L + base;
+    IMG_LOOP(p, H * W) {
+        if (!mm[p]) continue;
+        const int y = p / W, x = p - y * W;
+        if (x > 0 && mm[p - 1]) uf_union(LL, p, p - 1);
+        if (y > 0) {
+            if (mm[p - W]) uf_union(LL, p, p - W);
+            if (x > 0 && mm[p - W - 1]) uf_union(LL, p, p - W - 1);
+            if (x < W - 1 && mm[p - W + 1]) uf_union(LL, p, p - W + 1);
+        }
+    }
+}
+__global__ void ccl_compress_kernel(int *__restrict__ L, int npx)
+{
+    const size_t base = (size_t)blockIdx.y * npx;
+    IMG_LOOP(p, npx) { if (L[base + p] >= 0) L[base + p] = uf_find(L + base, p); }
+}
+
+// ---- per-label area and perimeter code counts (skimage regionprops.perimeter, 4-neighbourhood) ----
+__device__ __forceinline__ int lab_at(const int *L, int H, int W, int y, int x) { return (y < 0 || y >= H || x < 0 || x >= W) ? -1 : L[y * W + x]; }
+__device__ __forceinline__ bool is_border(const int *L, int H, int W, int y, int x, int l)
+{
+    if (lab_at(L, H, W, y, x) != l) return false;
+    return lab_at(L, H, W, y - 1, x) != l || lab_at(L, H, W, y + 1, x) != l || lab_at(L, H, W, y, x - 1) != l || lab_at(L, H, W, y, x + 1) != l;
+}
+__global__ void region_stats_kernel(const int *__restrict__ L, int H, int W, int *__restrict__ area, int *__restrict__ n1,
+                                    int *__restrict__ n2, int *__restrict__ n3)
+{
+    const size_t base = (size_t)blockIdx.y * H * W;
+    const int *LL = L + base;
+    IMG_LOOP(p, H * W) {
+        const int l = LL[p];
+        if (l < 0) continue;
+        atomicAdd(&area[base + l], 1);
+        const int y = p / W, x = p - y * W;
+        if (!is_border(LL, H, W, y, x, l)) continue;
+        const int code = 1 + 2 * (is_border(LL, H, W, y - 1, x, l) + is_border(LL, H, W, y + 1, x, l) + is_border(LL, H, W, y, x - 1, l) + is_border(LL, H, W, y, x + 1, l)) +
+                         10 * (is_border(LL, H, W, y - 1, x - 1, l) + is_border(LL, H, W, y - 1, x + 1, l) + is_border(LL, H, W, y + 1, x - 1, l) + is_border(LL, H, W, y + 1, x + 1, l));
+        if (code == 5 || code == 7 || code == 15 || code == 17 || code == 25 || code == 27) atomicAdd(&n1[base + l], 1);
+        else if (code == 21 || code == 33) atomicAdd(&n2[base + l], 1);
+        else if (code == 13 || code == 23) atomicAdd(&n3[base + l], 1);
+    }
+}
+
+// ---- Zhang thinning: one parallel sub-iteration (reads `in`, writes `out`, raises changed[img]) ----
+__global__ void zhang_pass_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int H, int W, int pass,
+                                  int *__restrict__ changed, const int *__restrict__ done)
+{
+    if (done[blockIdx.y]) return;                 // this image converged earlier (its result sits in the pair's input buffer)
+    const size_t base = (size_t)blockIdx.y * H * W;
+    const uint8_t *s = in + base;
+    bool any = false;
+    IMG_LOOP(p, H * W) {
+        uint8_t v = s[p];
+        if (v) {
+            const int y = p / W, x = p - y * W;
+            auto at = [&](int yy, int xx) -> int { return (yy < 0 || yy >= H || xx < 0 || xx >= W) ? 0 : s[yy * W + xx]; };
+            const int code = at(y - 1, x - 1) + 2 * at(y - 1, x) + 4 * at(y - 1, x + 1) + 8 * at(y, x + 1) + 16 * at(y + 1, x + 1) +
+                             32 * at(y + 1, x) + 64 * at(y + 1, x - 1) + 128 * at(y, x - 1);
+            const int t = d_skel_lut[code];
+            if (t == 3 || (t == 1 && pass == 0) || (t == 2 && pass == 1)) { v = 0; any = true; }
+        }
+        out[base + p] = v;
+    }
+    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(&changed[blockIdx.y], 1);
+}
+
+// after each (first, second) pair: an image whose pair removed nothing is done
+__global__ void zhang_check_kernel(int *__restrict__ changed, int *__restrict__ done, int k)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    if (!changed[i]) done[i] = 1;
+    changed[i] = 0;
+}
+
+// ---- skeleton components: fork flag and decision per skeleton root -> drop flag per mask root ----
+__global__ void skel_fork_kernel(const uint8_t *__restrict__ sk, const int *__restrict__ SL, int H, int W, int *__restrict__ has_fork)
+{
+    const size_t base = (size_t)blockIdx.y * H * W;
+    const uint8_t *s = sk + base;
+    IMG_LOOP(p, H * W) {
+        if (!s[p]) continue;
+        const int y = p / W, x = p - y * W;
+        int deg = 0;
+        for (int a = -1; a <= 1; a++)
+            for (int b = -1; b <= 1; b++) {
+                const int yy = y + a, xx = x + b;
+                if ((a | b) == 0 || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                deg += s[yy * W + xx];
+            }
+        if (deg > 2) atomicOr(&has_fork[base + SL[base + p]], 1);
+    }
+}
+__global__ void decide_kernel(const int *__restrict__ SL, const int *__restrict__ ML, const int *__restrict__ has_fork,
+                              const int *__restrict__ area, const int *__restrict__ n1, const int *__restrict__ n2,
+                              const int *__restrict__ n3, int npx, int remove_isolated, int *__restrict__ drop)
+{
+    const size_t base = (size_t)blockIdx.y * npx;
+    const double SQ2 = sqrt(2.0);
+    IMG_LOOP(p, npx) {
+        if (SL[base + p] != p) continue;                 // one decision per skeleton component (its root pixel)
+        const int l = ML[base + p];                      // mask component of that pixel
+        const double per = (double)n1[base + l] + (double)n2[base + l] * SQ2 + (double)n3[base + l] * ((1 + SQ2) / 2);
+        const double circ = 4 * M_PI * (double)area[base + l] / (per * per + 1e-7);
+        if ((remove_isolated && !has_fork[base + p]) || circ > 0.8) drop[base + l] = 1;
+    }
+}
+__global__ void apply_drop_kernel(const uint8_t *__restrict__ m, const int *__restrict__ ML, const int *__restrict__ drop,
+                                  uint8_t *__restrict__ out, int npx)
+{
+    const size_t base = (size_t)blockIdx.y * npx;
+    IMG_LOOP(p, npx) out[base + p] = m[base + p] && !drop[base + ML[base + p]];
+}
+
+// ---- exact EDT (Meijster): columns, then rows; squared distances are exact integers ----
+__global__ void edt_cols_kernel(const uint8_t *__restrict__ m, int *__restrict__ g, int H, int W, int *__restrict__ any_zero)
+{
+    const int img = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= W) return;
+    const uint8_t *mm = m + (size_t)img * H * W;
+    int *gg = g + (size_t)img * H * W;
+    const int INF = 1 << 20;
+    bool zero = false;
+    int prev = mm[x] ? INF : 0;
+    zero |= !mm[x];
+    gg[x] = prev;
+    for (int y = 1; y < H; y++) {
+        const bool fg = mm[(size_t)y * W + x];
+        zero |= !fg;
+        prev = fg ? min(INF, prev + 1) : 0;
+        gg[(size_t)y * W + x] = prev;
+    }
+    for (int y = H - 2; y >= 0; y--) {
+        const int below = gg[(size_t)(y + 1) * W + x], cur = gg[(size_t)y * W + x];
+        if (below < cur) gg[(size_t)y * W + x] = min(cur, below + 1);
+    }
+    if (zero) atomicOr(&any_zero[img], 1);
+}
+__global__ void edt_rows_kernel(const int *__restrict__ g, int H, int W, const int *__restrict__ any_zero, int *__restrict__ st,
+                                double *__restrict__ dist)
+{
+    const int img = blockIdx.y;
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= H) return;
+    double *dd = dist + ((size_t)img * H + y) * W;
+    if (!any_zero[img]) {     // scipy quirk without background: distance to the virtual pixel (-1, 0)
+        for (int x = 0; x < W; x++) dd[x] = sqrt((double)((long long)(y + 1) * (y + 1) + (long long)x * x));
+        return;
+    }
+    const int *gr = g + ((size_t)img * H + y) * W;
+    int *s = st + ((size_t)img * H + y) * 2 * W, *t = s + W;
+    auto f = [&](int x, int i) -> long long { const long long gi = gr[i]; return (long long)(x - i) * (x - i) + gi * gi; };
+    auto sep = [&](int i, int u) -> long long {
+        const long long gu = gr[u], gi = gr[i];
+        return ((long long)u * u - (long long)i * i + gu * gu - gi * gi) / (2 * (long long)(u - i));
+    };
+    int q = 0;
+    s[0] = 0; t[0] = 0;
+    for (int u = 1; u < W; u++) {
+        while (q >= 0 && f(t[q], s[q]) > f(t[q], u)) q--;
+        if (q < 0) { q = 0; s[0] = u; }
+        else {
+            const long long w = 1 + sep(s[q], u);
+            if (w < W) { q++; s[q] = u; t[q] = (int)w; }
+        }
+    }
+    for (int u = W - 1; u >= 0; u--) {
+        dd[u] = sqrt((double)f(u, s[q]));
+        if (u == t[q]) q--;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// driver
+// ---------------------------------------------------------------------------------------------
+size_t morph_workspace_bytes(int k, int H, int W)
+{
+    const size_t npx = (size_t)k * H * W;
+    // seg, med, skA, skB (u8) + ML, SL, g, area, n1, n2, n3, fork, drop (int) + st (2 ints) + flags
+    return npx * 4 + npx * sizeof(int) * 11 + 3 * (size_t)k * sizeof(int) + 4096;
+}
+const int *morph_done_flags(void *workspace, int k, int H, int W)
+{
+    const size_t n = (size_t)k * H * W;
+    uint8_t *skB = (uint8_t *)workspace + 3 * n;
+    int *ML = (int *)(((uintptr_t)(skB + n) + 15) & ~(uintptr_t)15);
+    return ML + 11 * n + 2 * k;
+}
+
+int filter_edt_dev(const double *pred, int k, int H, int W, int remove_isolated, void *workspace, uint8_t *filt_out,
+                   double *dist_out, hipStream_t s)
+{
+    if (!upload_lut()) { set_error("morph: cannot upload the skeletonize table"); return -2; }
+    const int npx = H * W;
+    const size_t n = (size_t)k * npx;
+    uint8_t *seg = (uint8_t *)workspace, *med = seg + n, *skA = med + n, *skB = skA + n;
+    int *ML = (int *)(((uintptr_t)(skB + n) + 15) & ~(uintptr_t)15);
+    int *SL = ML + n, *g = SL + n, *area = g + n, *n1 = area + n, *n2 = n1 + n, *n3 = n2 + n, *fork = n3 + n, *drop = fork + n;
+    int *st = drop + n;                 // 2n ints
+    int *flags = st + 2 * n;            // [0,k): zhang changed, [k,2k): any_zero, [2k,3k): zhang done
+    const dim3 grid((npx + 255) / 256 < 1024 ? (npx + 255) / 256 : 1024, k), blk(256);
+
+    hipLaunchKernelGGL(threshold_kernel, grid, blk, 0, s, pred, seg, npx);
+    hipLaunchKernelGGL(median13_kernel, grid, blk, 0, s, seg, med, H, W);
+    // labels of the median-filtered mask
+    hipLaunchKernelGGL(ccl_init_kernel, grid, blk, 0, s, med, ML, npx);
+    hipLaunchKernelGGL(ccl_merge_kernel, grid, blk, 0, s, med, ML, H, W);
+    hipLaunchKernelGGL(ccl_compress_kernel, grid, blk, 0, s, ML, npx);
+    if (hipMemsetAsync(area, 0, n * sizeof(int) * 6, s) != hipSuccess) { set_error("morph: memset"); return -2; }   // area,n1,n2,n3,fork,drop
+    hipLaunchKernelGGL(region_stats_kernel, grid, blk, 0, s, ML, H, W, area, n1, n2, n3);
+    // Zhang thinning to convergence: (first, second) sub-iteration pairs until a whole pair removes nothing
+    if (hipMemcpyAsync(skA, med, n, hipMemcpyDeviceToDevice, s) != hipSuccess) { set_error("morph: copy"); return -2; }
+    // No host round trip: every image carries a device-side `done` flag, converged images skip the remaining launches.
+    // A component of width w needs about w/2 pairs; max(H, W)/2 + 8 pairs always suffice (checked by the caller
+    // through flags[2k..3k) == 1, copied back with the results).
+    int *chg = flags, *done = flags + 2 * k;
+    if (hipMemsetAsync(flags, 0, 3 * k * sizeof(int), s) != hipSuccess) { set_error("morph: memset"); return -2; }
+    const int max_pairs = (H > W ? H : W) / 2 + 8;
+    for (int it = 0; it < max_pairs; it++) {
+        hipLaunchKernelGGL(zhang_pass_kernel, grid, blk, 0, s, skA, skB, H, W, 0, chg, done);
+        hipLaunchKernelGGL(zhang_pass_kernel, grid, blk, 0, s, skB, skA, H, W, 1, chg, done);
+        hipLaunchKernelGGL(zhang_check_kernel, dim3((k + 63) / 64), dim3(64), 0, s, chg, done, k);
+    }
+    // skeleton components, fork test, decision, filtered mask
+    hipLaunchKernelGGL(ccl_init_kernel, grid, blk, 0, s, skA, SL, npx);
+    hipLaunchKernelGGL(ccl_merge_kernel, grid, blk, 0, s, skA, SL, H, W);
+    hipLaunchKernelGGL(ccl_compress_kernel, grid, blk, 0, s, SL, npx);
+    hipLaunchKernelGGL(skel_fork_kernel, grid, blk, 0, s, skA, SL, H, W, fork);
+    hipLaunchKernelGGL(decide_kernel, grid, blk, 0, s, SL, ML, fork, area, n1, n2, n3, npx, remove_isolated, drop);
+    hipLaunchKernelGGL(apply_drop_kernel, grid, blk, 0, s, med, ML, drop, filt_out, npx);
+    // exact EDT of the filtered mask
+    if (hipMemsetAsync(flags + k, 0, k * sizeof(int), s) != hipSuccess) { set_error("morph: memset"); return -2; }
+    hipLaunchKernelGGL(edt_cols_kernel, dim3((W + 63) / 64, k), dim3(64), 0, s, filt_out, g, H, W, flags + k);
+    hipLaunchKernelGGL(edt_rows_kernel, dim3((H + 63) / 64, k), dim3(64), 0, s, g, H, W, flags + k, st, dist_out);
+    if (hipGetLastError() != hipSuccess) { set_error("morph: kernel launch failed"); return -2; }
+    return 0;
+}
+
+}  // namespace tmat

@@ -12,6 +12,7 @@
 #include "../../include/tmat.h"
 #include "tmat_ctx.h"
 #include "postproc.h"
+#include "morph.h"
 
 #include <algorithm>
 #include <atomic>
@@ -49,9 +50,15 @@ static int ensure_pass_buffers(Ctx *c, int K, int H, int W, int h, int w)
     TMAT_HIP(hipMalloc((void **)&b.small, (size_t)K * h * w * sizeof(uint16_t)));
     TMAT_HIP(hipMalloc((void **)&b.x, (size_t)K * h * w * sizeof(float)));
     TMAT_HIP(hipMalloc((void **)&b.mn, (size_t)K * sizeof(int))); TMAT_HIP(hipMalloc((void **)&b.mx, (size_t)K * sizeof(int)));
+    TMAT_HIP(hipMalloc(&b.morph_ws, morph_workspace_bytes(K, h, w)));
     for (int i = 0; i < 2; i++) {
         TMAT_HIP(hipMalloc((void **)&b.pred[i], (size_t)K * h * w * sizeof(double)));
         TMAT_HIP(hipHostMalloc((void **)&b.pred_host[i], (size_t)K * h * w * sizeof(double), hipHostMallocDefault));
+        TMAT_HIP(hipMalloc((void **)&b.filt[i], (size_t)K * h * w));
+        TMAT_HIP(hipMalloc((void **)&b.dist[i], (size_t)K * h * w * sizeof(double)));
+        TMAT_HIP(hipHostMalloc((void **)&b.filt_host[i], (size_t)K * h * w, hipHostMallocDefault));
+        TMAT_HIP(hipHostMalloc((void **)&b.dist_host[i], (size_t)K * h * w * sizeof(double), hipHostMallocDefault));
+        TMAT_HIP(hipHostMalloc((void **)&b.conv_host[i], (size_t)K * sizeof(int), hipHostMallocDefault));
         TMAT_HIP(hipEventCreateWithFlags(&b.done[i], hipEventDisableTiming));
     }
     b.K = K; b.H = H; b.W = W; b.h = h; b.w = w;
@@ -96,7 +103,15 @@ static int enqueue_back(Ctx *c, int k, int slot, const TileGeom &g)
     int rc = unet_up_dev(c, c->dout[slot], k * g.tiles_per_img, c->patch_out, s);
     if (rc) return rc;
     launch_blend(c->patch_out, c->win1d, k, g, b.pred[slot], s);
-    TMAT_HIP(hipMemcpyAsync(b.pred_host[slot], b.pred[slot], (size_t)k * b.h * b.w * sizeof(double), hipMemcpyDeviceToHost, s));
+    // binary morphology on the GPU: threshold, median, labelling, perimeter, thinning, fork test, EDT (remove_isolated=True
+    // is filter_branch_seg_mask's default, compute_branches.py:337)
+    rc = filter_edt_dev(b.pred[slot], k, b.h, b.w, 1, b.morph_ws, b.filt[slot], b.dist[slot], s);
+    if (rc) return TMAT_E_HIP;
+    const size_t npx = (size_t)k * b.h * b.w;
+    TMAT_HIP(hipMemcpyAsync(b.pred_host[slot], b.pred[slot], npx * sizeof(double), hipMemcpyDeviceToHost, s));
+    TMAT_HIP(hipMemcpyAsync(b.filt_host[slot], b.filt[slot], npx, hipMemcpyDeviceToHost, s));
+    TMAT_HIP(hipMemcpyAsync(b.dist_host[slot], b.dist[slot], npx * sizeof(double), hipMemcpyDeviceToHost, s));
+    TMAT_HIP(hipMemcpyAsync(b.conv_host[slot], morph_done_flags(b.morph_ws, k, b.h, b.w), k * sizeof(int), hipMemcpyDeviceToHost, s));
     TMAT_HIP(hipEventRecord(b.done[slot], s));
     return TMAT_OK;
 }
@@ -111,12 +126,13 @@ struct GraphParams {
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static bool trace_on() { static int t = -1; if (t < 0) { const char *e = getenv("TMAT_TRACE"); t = e && atoi(e) > 0; } return t; }
 
-static int analyze_host_image(const double *pred, int h, int w, const GraphParams &gp, tmat_row *row)
+static int analyze_host_image(const double *pred, const uint8_t *filt, const double *dist, int h, int w, const GraphParams &gp,
+                              tmat_row *row)
 {
     const size_t nf = (size_t)gp.fh * gp.fw;
     std::vector<float> field(nf), f255(nf);
     const double t0 = now_s();
-    postprocess_image(pred, h, w, gp.fh, gp.fw, field.data());
+    postprocess_from_filtered(pred, filt, dist, h, w, gp.fh, gp.fw, field.data());
     const double t1 = now_s();
     rescale255_f32(field.data(), nf, f255.data());
     const int cap_v = (int)nf + 4, cap_e = 3 * (int)nf + 4;
@@ -150,16 +166,18 @@ static int n_workers(int k)
     return std::max(1, std::min(hw, k));
 }
 
-static void start_host_job(HostJob &job, const double *pred_host, int k, int h, int w, const GraphParams gp, tmat_row *rows)
+static void start_host_job(HostJob &job, const double *pred_host, const uint8_t *filt_host, const double *dist_host, int k, int h,
+                           int w, const GraphParams gp, tmat_row *rows)
 {
     job.next = 0;
     const int nt = n_workers(k);
     for (int t = 0; t < nt; t++)
-        job.threads.emplace_back([&job, pred_host, k, h, w, gp, rows]() {
+        job.threads.emplace_back([&job, pred_host, filt_host, dist_host, k, h, w, gp, rows]() {
             for (;;) {
                 const int i = job.next.fetch_add(1);
                 if (i >= k) break;
-                int rc = analyze_host_image(pred_host + (size_t)i * h * w, h, w, gp, &rows[i]);
+                const size_t o = (size_t)i * h * w;
+                int rc = analyze_host_image(pred_host + o, filt_host + o, dist_host + o, h, w, gp, &rows[i]);
                 if (rc) job.rc = rc;
             }
         });
@@ -196,7 +214,10 @@ static int analyze_dev(Ctx *c, const uint16_t *imgs_dev, int n, int H, int W, do
                     p + 1, P, cnt(p), (tw1 - tw0) * 1e3, (now_s() - tw1) * 1e3);
         if (p + 1 < P && !rc) rc = enqueue_back(c, cnt(p + 1), slot ^ 1, g);
         if (p + 2 < P && !rc) rc = enqueue_front(c, img_at(p + 2), cnt(p + 2), slot, g);
-        if (!rc) start_host_job(jobs[slot], c->pass.pred_host[slot], cnt(p), h, w, gp, rows + (size_t)p * K);
+        for (int i = 0; i < cnt(p) && !rc; i++)
+            if (!c->pass.conv_host[slot][i]) { set_error("analyze: Zhang thinning did not converge within its launch budget"); rc = TMAT_E_HIP; }
+        if (!rc) start_host_job(jobs[slot], c->pass.pred_host[slot], c->pass.filt_host[slot], c->pass.dist_host[slot], cnt(p), h, w, gp,
+                                rows + (size_t)p * K);
     }
     for (auto &j : jobs) { j.join(); if (j.rc && !rc) rc = j.rc; }
     hipStreamSynchronize(c->stream2);
@@ -234,6 +255,29 @@ int tmat_segment_batch(tmat_handle hd, const uint16_t *imgs, int n, int H, int W
         std::memcpy(pred + (size_t)i0 * h * w, c->pass.pred_host[0], (size_t)k * h * w * sizeof(double));
     }
     hipFree(dimg);
+    return rc;
+}
+
+int tmat_filter_edt_batch(tmat_handle hd, const double *pred, int n, int hh, int ww, uint8_t *filtered, double *dist)
+{
+    Ctx *c = (Ctx *)hd;
+    if (!c || !pred || !filtered || !dist || n < 0 || hh < 1 || ww < 1) { set_error("tmat_filter_edt_batch: bad argument"); return TMAT_E_ARG; }
+    if (n == 0) return TMAT_OK;
+    TMAT_HIP(hipSetDevice(c->device));
+    const size_t npx = (size_t)n * hh * ww;
+    double *dp = nullptr, *dd = nullptr; uint8_t *df = nullptr; void *ws = nullptr;
+    int rc = TMAT_OK;
+    std::vector<int> conv(n, 0);
+    if (!hip_ok(hipMalloc((void **)&dp, npx * 8), "hipMalloc") || !hip_ok(hipMalloc((void **)&dd, npx * 8), "hipMalloc") ||
+        !hip_ok(hipMalloc((void **)&df, npx), "hipMalloc") || !hip_ok(hipMalloc(&ws, morph_workspace_bytes(n, hh, ww)), "hipMalloc")) rc = TMAT_E_HIP;
+    if (!rc && !hip_ok(hipMemcpyAsync(dp, pred, npx * 8, hipMemcpyHostToDevice, c->stream), "H2D")) rc = TMAT_E_HIP;
+    if (!rc && filter_edt_dev(dp, n, hh, ww, 1, ws, df, dd, c->stream)) rc = TMAT_E_HIP;
+    if (!rc && (!hip_ok(hipMemcpyAsync(filtered, df, npx, hipMemcpyDeviceToHost, c->stream), "D2H") ||
+                !hip_ok(hipMemcpyAsync(dist, dd, npx * 8, hipMemcpyDeviceToHost, c->stream), "D2H") ||
+                !hip_ok(hipMemcpyAsync(conv.data(), morph_done_flags(ws, n, hh, ww), n * sizeof(int), hipMemcpyDeviceToHost, c->stream), "D2H") ||
+                !hip_ok(hipStreamSynchronize(c->stream), "sync"))) rc = TMAT_E_HIP;
+    for (int i = 0; i < n && !rc; i++) if (!conv[i]) { set_error("tmat_filter_edt_batch: thinning did not converge"); rc = TMAT_E_HIP; }
+    hipFree(dp); hipFree(dd); hipFree(df); hipFree(ws);
     return rc;
 }
 

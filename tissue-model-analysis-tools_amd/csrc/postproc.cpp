@@ -387,8 +387,15 @@ static const uint8_t *medial_table()
 
 void medial_axis(const uint8_t *m, int H, int W, uint8_t *skel, double *dist)
 {
-    const uint8_t *table = medial_table();
     edt(m, H, W, dist);
+    medial_axis_thin(m, dist, H, W, skel);
+}
+
+// the ordered thinning of medial_axis given the mask's EDT (sequential by construction: every decision reads the
+// current state of the 3x3 neighbourhood)
+void medial_axis_thin(const uint8_t *m, const double *dist, int H, int W, uint8_t *skel)
+{
+    const uint8_t *table = medial_table();
     const int Wp = W + 2;
     std::vector<uint8_t> res((size_t)(H + 2) * Wp, 0);
     std::vector<int32_t> pos;
@@ -488,7 +495,20 @@ void resize_aa(const double *img, int H, int W, int oh, int ow, float *out)
         }
 }
 
-// compute_branches.py:334-357 for one image (no well mask)
+// compute_branches.py:340-357 for one image, given the filtered mask and its EDT from the GPU (morph_kernels.hip)
+void postprocess_from_filtered(const double *pred, const uint8_t *filt, const double *dist, int H, int W, int oh, int ow, float *field)
+{
+    const size_t n = (size_t)H * W;
+    std::vector<uint8_t> skel(n), nskel(n);
+    std::vector<double> cdt(n), wt(n);
+    medial_axis_thin(filt, dist, H, W, skel.data());
+    for (size_t i = 0; i < n; i++) nskel[i] = !skel[i];
+    edt(nskel.data(), H, W, cdt.data());
+    for (size_t i = 0; i < n; i++) wt[i] = pred[i] * (dist[i] / (dist[i] + cdt[i]));
+    resize_aa(wt.data(), H, W, oh, ow, field);
+}
+
+// compute_branches.py:334-357 for one image (no well mask), host only
 void postprocess_image(const double *pred, int H, int W, int oh, int ow, float *field)
 {
     const size_t n = (size_t)H * W;

@@ -31,6 +31,13 @@ struct PassBuf {
     int *mn = nullptr, *mx = nullptr;
     double *pred[2] = {nullptr, nullptr};
     double *pred_host[2] = {nullptr, nullptr};
+    // GPU morphology outputs (morph_kernels.hip): filtered mask, its EDT, per-image convergence flags
+    void *morph_ws = nullptr;
+    uint8_t *filt[2] = {nullptr, nullptr};
+    double *dist[2] = {nullptr, nullptr};
+    uint8_t *filt_host[2] = {nullptr, nullptr};
+    double *dist_host[2] = {nullptr, nullptr};
+    int *conv_host[2] = {nullptr, nullptr};
     hipEvent_t done[2] = {nullptr, nullptr};
 };
 
@@ -59,10 +66,14 @@ struct Ctx {
     void free_pass()
     {
         PassBuf &b = pass;
-        void *dev[] = {b.xi, b.yi, b.xc, b.yc, b.tmp, b.x, b.small, b.mn, b.mx, b.pred[0], b.pred[1]};
+        void *dev[] = {b.xi, b.yi, b.xc, b.yc, b.tmp, b.x, b.small, b.mn, b.mx, b.pred[0], b.pred[1], b.morph_ws,
+                       b.filt[0], b.filt[1], b.dist[0], b.dist[1]};
         for (void *p : dev) if (p) hipFree(p);
         for (int i = 0; i < 2; i++) {
             if (b.pred_host[i]) hipHostFree(b.pred_host[i]);
+            if (b.filt_host[i]) hipHostFree(b.filt_host[i]);
+            if (b.dist_host[i]) hipHostFree(b.dist_host[i]);
+            if (b.conv_host[i]) hipHostFree(b.conv_host[i]);
             if (b.done[i]) hipEventDestroy(b.done[i]);
         }
         pass = PassBuf();

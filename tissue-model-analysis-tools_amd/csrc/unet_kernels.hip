@@ -26,9 +26,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   (BM/WM) x (BN/WN) outputs as TM x TN tiles of 32x32 (16 accumulator VGPRs each).
 //   Register-prefetch double buffering: one barrier per K chunk.
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int KC>
+template <int BM, int BN, int WM, int WN, int KC, int KS>
 __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_mfma_kernel(ConvArgs a, int M, int Ho, int Wo, int nMt, int nNt)
 {
+    // KS (1 or 3) is a template parameter so that the 3x3 and the pointwise instantiations are distinct kernels
+    // (distinct names in rocprofv3 traces: the 3x3 <128,128,2,2,32,3> instantiation is the dominant kernel).
     static_assert(WM * WN == 4, "4 waves");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LDA = BM + 1;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_mfma_kernel(Conv
     const int wm = wave / WN, wn = wave % WN;
 
     const int H = a.h << a.up, W = a.w << a.up;
-    const int taps = a.ksize * a.ksize;
+    constexpr int taps = KS * KS;
     const int cchunks = a.Cin / KC;
     const int nchunks = taps * cchunks;
 
@@ -116,8 +118,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_mfma_kernel(Conv
 #define TMAT_LOAD_CHUNK(S)                                                             \
     {                                                                                  \
         if (ld_c0 == 0) {                                                              \
-            const int dy = a.ksize == 3 ? ld_tap / 3 - 1 : 0;                          \
-            const int dx = a.ksize == 3 ? ld_tap % 3 - 1 : 0;                          \
+            const int dy = KS == 3 ? ld_tap / 3 - 1 : 0;                          \
+            const int dx = KS == 3 ? ld_tap % 3 - 1 : 0;                          \
             TMAT_BASE(0, ab0) TMAT_BASE(1, ab1) TMAT_BASE(2, ab2) TMAT_BASE(3, ab3)    \
             TMAT_BASE(4, ab4) TMAT_BASE(5, ab5) TMAT_BASE(6, ab6) TMAT_BASE(7, ab7)    \
         }                                                                              \
@@ -269,7 +271,10 @@ static void launch_conv_cfg(const ConvArgs &a, int M, int Ho, int Wo, hipStream_
 {
     int nMt = (M + BM - 1) / BM, nNt = a.Cout / BN;
     int grid = ((nMt + 7) / 8) * 8 * nNt;
-    hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KC>), dim3(grid), dim3(256), 0, s, a, M, Ho, Wo, nMt, nNt);
+    if (a.ksize == 3)
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KC, 3>), dim3(grid), dim3(256), 0, s, a, M, Ho, Wo, nMt, nNt);
+    else
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KC, 1>), dim3(grid), dim3(256), 0, s, a, M, Ho, Wo, nMt, nNt);
 }
 
 bool launch_conv(const ConvArgs &a, hipStream_t s)
