@@ -177,6 +177,12 @@ def main():
         total_images = n_img * world * args.steps
         value = total_images / elapsed
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        # HBM traffic of the dominant kernel comes from the committed PMC summary of the same pipeline (separate
+        # rocprofv3 --pmc passes, tools/profile_round.sh); it is per launch of 1600 patches, like `achieved`
+        traffic = None
+        summ = sorted((REPO / "profiles").glob("r*_summary.json"))
+        if summ and args.max_patches == 1600:
+            traffic = json.loads(summ[-1].read_text()).get("traffic_bytes_per_launch")
         out = {
             "metric": "images/sec (1024x1024 uint16) through compute_branches",
             "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -187,7 +193,7 @@ def main():
                                    "default_branching_computation.json", "images_per_gpu": n_img, "patches_per_image": 200,
                        "rows_gathered": n_rows, "host_threads": int(os.environ["TMAT_HOST_THREADS"])},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                          "kernel": "tmat::conv_mfma_kernel<128, 128, 2, 2, 32, 3> (3x3 implicit-GEMM on v_mfma_f32_32x32x2_f32; "
                                    "6 of the 8 transposed-conv layers, 75 % of the 3x3 FLOPs)",
                          "launches": int(conv_launches), "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4)},

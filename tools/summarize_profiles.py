@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/profiles_<round>/ (tools/profile_round.sh) into the committed profiles/<round>_* files:
+the rocprofv3 --kernel-trace --stats table, the bench lines, and a JSON summary with the dominant kernel's
+average duration and its per-launch HBM traffic from the PMC passes (FETCH_SIZE doubled as
+MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as read; both are in KiB)."""
+import collections
+import csv
+import json
+import shutil
+import sys
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parents[1]
+DOM = "conv_mfma_kernel<128, 128, 2, 2, 32, 3>"
+
+
+def main(rnd):
+    src = REPO / "gpurun_out" / f"profiles_{rnd}"
+    dst = REPO / "profiles"
+    dst.mkdir(exist_ok=True)
+    for name in ("kernel_stats.csv", "bench.json", "bench.err", "bench_under_rocprof.json"):
+        if (src / name).exists():
+            shutil.copy(src / name, dst / f"{rnd}_{name}")
+    out = {"round": rnd, "dominant_kernel": "tmat::" + DOM}
+    for r in csv.DictReader(open(src / "kernel_stats.csv")):
+        if DOM in r["Name"]:
+            out["rocprof_calls"] = int(r["Calls"])
+            out["rocprof_avg_ms"] = float(r["AverageNs"]) / 1e6
+            out["rocprof_total_ms"] = float(r["TotalDurationNs"]) / 1e6
+            out["rocprof_percentage"] = float(r["Percentage"])
+    bench = json.loads((src / "bench.json").read_text().strip().splitlines()[-1])
+    out["bench_value_images_per_s"] = bench["value"]
+    out["bench_roofline"] = bench["roofline"]
+    out["bench_cpu_baseline"] = bench.get("cpu_baseline")
+
+    def counter(tag, cname):
+        vals = []
+        p = src / f"pmc_{tag}.csv"
+        if not p.exists():
+            return vals
+        for r in csv.DictReader(open(p)):
+            if r["Counter_Name"] == cname and DOM in r["Kernel_Name"]:
+                vals.append(float(r["Counter_Value"]))
+        return vals
+
+    f = counter("FETCH_SIZE", "FETCH_SIZE")
+    w = counter("WRITE_SIZE", "WRITE_SIZE")
+    if f and w:
+        fetch = 2.0 * sum(f) / len(f) * 1024.0          # gfx950: FETCH_SIZE reports half the bytes of wide coalesced reads
+        write = sum(w) / len(w) * 1024.0
+        out["pmc_launches"] = len(f)
+        out["hbm_read_bytes_per_launch"] = fetch
+        out["hbm_write_bytes_per_launch"] = write
+        out["traffic_bytes_per_launch"] = fetch + write
+        out["traffic_note"] = ("mean over the launches of the dominant kernel in a 16-image run of the same pipeline "
+                               "(same 1600 patches per launch); FETCH_SIZE x2 per MI355X_MICROARCH.md, WRITE_SIZE as read")
+    mf = counter("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES")
+    ga = counter("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE")
+    if mf and ga:
+        out["mfma_busy_fraction"] = sum(mf) / (sum(ga) / 8.0 * 1024.0)
+    (dst / f"{rnd}_summary.json").write_text(json.dumps(out, indent=2) + "\n")
+    print(json.dumps(out, indent=2))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01")
