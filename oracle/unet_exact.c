@@ -4,7 +4,7 @@
  * CPU restatement of the inference graph of build_UNetXception
  * (reference fl_tissue_model_tools/models.py:110-166) with a FIXED arithmetic order:
  * every contraction is a k-ordered chain of single-rounding f32 fused multiply-adds,
- *     acc = fmaf(a[k], w[k], acc),   k = tap-major (ky, kx), then input channel ascending,
+ *     acc = fmaf(a[k], w[k], acc),   k = input-channel blocks of 32, inside a block tap-major (ky, kx), then channel,
  * which is bit-for-bit what v_mfma_f32_32x32x2_f32 computes on gfx950 when the K dimension
  * is walked in the same order.  The HIP path follows the same order, so GPU and oracle
  * outputs are compared bit-exactly.
@@ -79,14 +79,19 @@ static float *make_padded(const float *S, int N, int h, int w, int C, int up, in
 /* micro kernel: XB pixels x OB output channels, K = taps*Cin chain in order */
 #define XB 4
 #define OB 64
+#define CB 32
 CLONES static void conv_block(const float *const *ip /*[taps][XB] row ptrs*/, int taps, int Cin,
                               const float *Wc, int Cout, int o0, int ob, float acc[XB][OB])
 {
     for (int i = 0; i < XB; i++)
         for (int o = 0; o < OB; o++) acc[i][o] = 0.0f;
+    /* K order of the chain (shared with csrc/unet_kernels.hip): input channels in blocks of CB = 32; inside a
+       block tap-major (ky, kx), then channel ascending.  (Block-major order keeps the 3x3 window of a channel
+       block hot in cache / L2 across its 9 taps.) */
+    for (int cb = 0; cb < Cin; cb += CB)
     for (int t = 0; t < taps; t++) {
         const float *w = Wc + (size_t)t * Cin * Cout + o0;
-        for (int c = 0; c < Cin; c++) {
+        for (int c = cb; c < cb + CB && c < Cin; c++) {
             const float *wr = w + (size_t)c * Cout;
             if (ob == OB) {
                 for (int i = 0; i < XB; i++) {

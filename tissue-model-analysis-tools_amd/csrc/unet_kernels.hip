@@ -4,10 +4,11 @@
 // keras Model.predict at smooth_tiled_predictions.py:179.
 //
 // Arithmetic contract (shared with oracle/unet_exact.c, compared bit-exactly):
-//   every contraction is a chain acc = fmaf(a[k], w[k], acc) with k = (ky, kx) tap-major and
-//   input channel ascending; v_mfma_f32_32x32x2_f32 performs exactly that chain (one rounding
-//   per product, k ascending), so the dense 3x3 / 1x1 contractions run on the matrix cores at
-//   full f32 precision.  Epilogues: v = fmaf(acc, scale, shift) (folded BN) or acc + bias,
+//   every contraction is a chain acc = fmaf(a[k], w[k], acc); for the MFMA convolutions k walks the
+//   input channels in blocks of 32, inside a block tap-major (ky, kx), then channel ascending
+//   (depthwise / stem / final: tap-major, channel ascending); v_mfma_f32_32x32x2_f32 performs exactly
+//   such a chain (one rounding per product, k ascending), so the dense 3x3 / 1x1 contractions run on
+//   the matrix cores at full f32 precision.  Epilogues: v = fmaf(acc, scale, shift) (folded BN) or acc + bias,
 //   optional residual add, optional ReLU.  Compiled with -ffp-contract=off.
 #include "tmat_internal.h"
 #include "../../include/tmat.h"
@@ -106,8 +107,10 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_mfma_kernel(Conv
     static_assert(NPB == 4 || NPB == 2 || NPB == 1, "B passes");
     const float *ab0 = a.zeros, *ab1 = a.zeros, *ab2 = a.zeros, *ab3 = a.zeros, *ab4 = a.zeros, *ab5 = a.zeros, *ab6 = a.zeros,
                 *ab7 = a.zeros;
-    const float *wp = a.W + n0 + bcol + (size_t)brow * a.Cout;
-    int ld_tap = 0, ld_c0 = 0, ld_cc = 0;
+    const float *wbase = a.W + n0 + bcol + (size_t)brow * a.Cout;
+    // chunk order: 32-channel block major, then tap, then (KC = 16 only) the two halves of the block
+    constexpr int HPB = 32 / KC;            // chunks per (block, tap)
+    int ld_cb = 0, ld_tap = 0, ld_half = 0, ld_cc = 0;
 
 #define TMAT_BASE(i, AB)                                                                                    \
     if (i < NPA) {                                                                                          \
@@ -117,12 +120,14 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_mfma_kernel(Conv
     }
 #define TMAT_LOAD_CHUNK(S)                                                             \
     {                                                                                  \
-        if (ld_c0 == 0) {                                                              \
-            const int dy = KS == 3 ? ld_tap / 3 - 1 : 0;                          \
-            const int dx = KS == 3 ? ld_tap % 3 - 1 : 0;                          \
+        if (ld_half == 0 && ld_cc < nchunks) {                                         \
+            const int dy = KS == 3 ? ld_tap / 3 - 1 : 0;                               \
+            const int dx = KS == 3 ? ld_tap % 3 - 1 : 0;                               \
             TMAT_BASE(0, ab0) TMAT_BASE(1, ab1) TMAT_BASE(2, ab2) TMAT_BASE(3, ab3)    \
             TMAT_BASE(4, ab4) TMAT_BASE(5, ab5) TMAT_BASE(6, ab6) TMAT_BASE(7, ab7)    \
         }                                                                              \
+        const int ld_c0 = ld_cb * 32 + ld_half * KC;                                   \
+        const float *wp = wbase + ((size_t)ld_tap * a.Cin + ld_c0) * a.Cout;           \
         if (0 < NPA) S##a0 = *reinterpret_cast<const float4 *>(ab0 + ld_c0);           \
         if (1 < NPA) S##a1 = *reinterpret_cast<const float4 *>(ab1 + ld_c0);           \
         if (2 < NPA) S##a2 = *reinterpret_cast<const float4 *>(ab2 + ld_c0);           \
@@ -139,9 +144,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_mfma_kernel(Conv
            LDS store); past the last chunk the state simply stops advancing and the last chunk is re-read, unused */ \
         ld_cc++;                                                                       \
         if (ld_cc < nchunks) {                                                         \
-            wp += (size_t)KC * a.Cout;                                                 \
-            ld_c0 += KC;                                                               \
-            if (ld_c0 == a.Cin) { ld_c0 = 0; ld_tap++; }                               \
+            if (++ld_half == HPB) { ld_half = 0; if (++ld_tap == taps) { ld_tap = 0; ld_cb++; } } \
         }                                                                              \
     }
 #define TMAT_STORE_A(i, R)                                                             \
