@@ -75,21 +75,32 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_mfma_kernel(Conv
     const int cchunks = a.Cin / KC;
     const int nchunks = taps * cchunks;
 
-    // per-thread pixel bookkeeping for A staging
+    // per-thread pixel bookkeeping for A staging: pointer to the centre tap's pixel, a 9-bit mask of the taps that fall
+    // inside the image, and (for nearest-upsampled inputs) the parities of y and x
     const int c4 = (t % TPP) * 4;
-    int py[NPA], px[NPA], pbase[NPA];
-    bool pok[NPA];
+    const float *pc[NPA];
+    unsigned pm[NPA];
 #pragma unroll
     for (int i = 0; i < NPA; i++) {
-        int m = m0 + i * PPP + t / TPP;
-        pok[i] = m < M;
-        int mm = pok[i] ? m : 0;
-        int n = mm / (Ho * Wo);
-        int r = mm - n * (Ho * Wo);
-        int y = r / Wo;
-        py[i] = y * a.stride;
-        px[i] = (r - y * Wo) * a.stride;
-        pbase[i] = n * a.h;
+        const int m = m0 + i * PPP + t / TPP;
+        const bool ok = m < M;
+        const int mm = ok ? m : 0;
+        const int n = mm / (Ho * Wo);
+        const int r = mm - n * (Ho * Wo);
+        const int yo = r / Wo;
+        const int y = yo * a.stride, x = (r - yo * Wo) * a.stride;
+        pc[i] = a.in + ((size_t)(n * a.h + (y >> a.up)) * a.w + (x >> a.up)) * a.Cin + c4;
+        unsigned msk = 0;
+        if (ok) {
+            if (KS == 3) {
+#pragma unroll
+                for (int tp = 0; tp < 9; tp++) {
+                    const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) msk |= 1u << tp;
+                }
+            } else msk = 1u;
+        }
+        pm[i] = msk | ((unsigned)(y & 1) << 9) | ((unsigned)(x & 1) << 10);
     }
     const int brow = t / BV, bcol = (t % BV) * 4;
 
@@ -114,9 +125,11 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_mfma_kernel(Conv
 
 #define TMAT_BASE(i, AB)                                                                                    \
     if (i < NPA) {                                                                                          \
-        const int yy = py[i] + dy, xx = px[i] + dx;                                                         \
-        const bool ok = pok[i] && yy >= 0 && yy < H && xx >= 0 && xx < W;                                   \
-        AB = ok ? a.in + ((size_t)(pbase[i] + (yy >> a.up)) * a.w + (xx >> a.up)) * a.Cin + c4 : a.zeros + c4; \
+        /* tap offset in stored pixels: (dy, dx) itself, or ((parity + d) >> 1) for a nearest-upsampled input */ \
+        const int ddy = a.up ? (((int)((pm[i] >> 9) & 1u) + dy) >> 1) : dy;                                 \
+        const int ddx = a.up ? (((int)((pm[i] >> 10) & 1u) + dx) >> 1) : dx;                                \
+        const bool ok = (pm[i] >> ld_tap) & 1u;                                                             \
+        AB = ok ? pc[i] + (ddy * a.w + ddx) * a.Cin : a.zeros + c4;                                         \
     }
 #define TMAT_LOAD_CHUNK(S)                                                             \
     {                                                                                  \
