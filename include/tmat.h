@@ -86,6 +86,15 @@ int tmat_postprocess_batch(tmat_handle h, const double *pred, int n, int hh, int
 int tmat_filter_edt_batch(tmat_handle h, const double *pred, int n, int hh, int ww, uint8_t *filtered, double *dist);
 
 /*
+ * The GPU stages after the medial-axis thinning (csrc/finish_kernels.hip): centerline_dt = EDT(~skel),
+ * pred *= dist / (dist + centerline_dt) (compute_branches.py:341-344), skimage resize to (out_h, out_w)
+ * (order 1, anti-aliased, :351-357) -> field f32, and rescale_intensity(field, (0, 255)) (:419) -> field255 f32.
+ * pred, dist (n, h, w) f64; skel (n, h, w) u8; field, field255 (n, out_h, out_w) f32.
+ */
+int tmat_finish_batch(tmat_handle h, const double *pred, const double *dist, const uint8_t *skel, int n, int hh, int ww,
+                      int out_h, int out_w, float *field, float *field255);
+
+/*
  * fl_tissue_model_tools.dmtgraph.compute_dmt_graph(img, delta1, delta2) (reference
  * dmtgraph.py:38-99; the contract the un-vendored pydmtgraph C++ extension exposed).
  * img: (rows, cols) f32.  verts: (cap_v, 2) int32 [row, col]; edges: (cap_e, 2) int32.

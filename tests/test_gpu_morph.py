@@ -47,3 +47,25 @@ def test_batch_of_mixed_images(handle):
         want = morph.filter_branch_seg_mask(pred[i] > 0.5)
         assert np.array_equal(filt[i], want), i
         assert np.array_equal(dist[i], ndi.distance_transform_edt(want)), i
+
+
+@pytest.mark.parametrize("shape,out", [((96, 128), (72, 96)), ((128, 128), (128, 128)), ((200, 150), (96, 72)), ((64, 64), (100, 100))])
+def test_finish_stage_matches_oracle(handle, shape, out):
+    """a15-a17 on the GPU (EDT of the inverted skeleton, centre-line weighting, gaussian + linear zoom + clip,
+    rescale to 0..255) through tmat_finish_batch, bit for bit against oracle/morph.py"""
+    from oracle import morph
+    rs = np.random.RandomState(5)
+    masks = [ndi.gaussian_filter(rs.normal(size=shape), s) > t for s, t in ((3, 0.02), (5, 0.0))]
+    masks += [np.zeros(shape, bool), np.ones(shape, bool)]
+    pred = np.stack([as_pred(m, rs) for m in masks])
+    filt = [morph.filter_branch_seg_mask(p > 0.5) for p in pred]
+    sk_dist = [morph.medial_axis(f) for f in filt]
+    skel = np.stack([s for s, _ in sk_dist])
+    dist = np.stack([d for _, d in sk_dist])
+    field, f255 = handle.finish(pred, dist, skel, out)
+    for i in range(len(masks)):
+        want, _, wskel = morph.postprocess(pred[i], out)
+        assert np.array_equal(wskel, skel[i])
+        assert np.array_equal(field[i].view(np.uint32), want.view(np.uint32)), i
+        w255 = morph.rescale_intensity(want, (0, 255)).astype(np.float32)
+        assert np.array_equal(f255[i].view(np.uint32), np.ascontiguousarray(w255).view(np.uint32)), i

@@ -254,6 +254,14 @@ __global__ void edt_rows_kernel(const int *__restrict__ g, int H, int W, const i
     }
 }
 
+// exact EDT of `mask` (distance of every pixel to the nearest zero pixel): g (n ints), st (2n ints), any_zero (k ints) scratch
+void launch_edt(const uint8_t *mask, int k, int H, int W, int *g, int *st, int *any_zero, double *dist, hipStream_t s)
+{
+    hipMemsetAsync(any_zero, 0, k * sizeof(int), s);
+    hipLaunchKernelGGL(edt_cols_kernel, dim3((W + 63) / 64, k), dim3(64), 0, s, mask, g, H, W, any_zero);
+    hipLaunchKernelGGL(edt_rows_kernel, dim3((H + 63) / 64, k), dim3(64), 0, s, g, H, W, any_zero, st, dist);
+}
+
 // ---------------------------------------------------------------------------------------------
 // driver
 // ---------------------------------------------------------------------------------------------
@@ -313,9 +321,7 @@ int filter_edt_dev(const double *pred, int k, int H, int W, int remove_isolated,
     hipLaunchKernelGGL(decide_kernel, grid, blk, 0, s, SL, ML, fork, area, n1, n2, n3, npx, remove_isolated, drop);
     hipLaunchKernelGGL(apply_drop_kernel, grid, blk, 0, s, med, ML, drop, filt_out, npx);
     // exact EDT of the filtered mask
-    if (hipMemsetAsync(flags + k, 0, k * sizeof(int), s) != hipSuccess) { set_error("morph: memset"); return -2; }
-    hipLaunchKernelGGL(edt_cols_kernel, dim3((W + 63) / 64, k), dim3(64), 0, s, filt_out, g, H, W, flags + k);
-    hipLaunchKernelGGL(edt_rows_kernel, dim3((H + 63) / 64, k), dim3(64), 0, s, g, H, W, flags + k, st, dist_out);
+    launch_edt(filt_out, k, H, W, g, st, flags + k, dist_out, s);
     if (hipGetLastError() != hipSuccess) { set_error("morph: kernel launch failed"); return -2; }
     return 0;
 }

@@ -31,10 +31,10 @@ void launch_rescale01(const uint16_t *x, int n, size_t per, int *mn, int *mx, fl
 static int round_half_even(double v) { return (int)std::nearbyint(v); }
 
 // device / pinned buffers for one image geometry, cached on the handle
-static int ensure_pass_buffers(Ctx *c, int K, int H, int W, int h, int w)
+static int ensure_pass_buffers(Ctx *c, int K, int H, int W, int h, int w, int fh, int fw)
 {
     PassBuf &b = c->pass;
-    if (b.K >= K && b.H == H && b.W == W && b.h == h && b.w == w) return TMAT_OK;
+    if (b.K >= K && b.H == H && b.W == W && b.h == h && b.w == w && b.fh == fh && b.fw == fw) return TMAT_OK;
     c->free_pass();
     std::vector<int> xi, yi;
     std::vector<float> xc, yc;
@@ -51,6 +51,15 @@ static int ensure_pass_buffers(Ctx *c, int K, int H, int W, int h, int w)
     TMAT_HIP(hipMalloc((void **)&b.x, (size_t)K * h * w * sizeof(float)));
     TMAT_HIP(hipMalloc((void **)&b.mn, (size_t)K * sizeof(int))); TMAT_HIP(hipMalloc((void **)&b.mx, (size_t)K * sizeof(int)));
     TMAT_HIP(hipMalloc(&b.morph_ws, morph_workspace_bytes(K, h, w)));
+    TMAT_HIP(hipMalloc(&b.finish_ws, finish_workspace_bytes(K, h, w, fh, fw)));
+    for (int i = 0; i < 2; i++) {
+        TMAT_HIP(hipMalloc((void **)&b.skel[i], (size_t)K * h * w));
+        TMAT_HIP(hipHostMalloc((void **)&b.skel_host[i], (size_t)K * h * w, hipHostMallocDefault));
+        TMAT_HIP(hipMalloc((void **)&b.field[i], (size_t)K * fh * fw * sizeof(float)));
+        TMAT_HIP(hipMalloc((void **)&b.f255[i], (size_t)K * fh * fw * sizeof(float)));
+        TMAT_HIP(hipHostMalloc((void **)&b.f255_host[i], (size_t)K * fh * fw * sizeof(float), hipHostMallocDefault));
+    }
+    b.fh = fh; b.fw = fw;
     for (int i = 0; i < 2; i++) {
         TMAT_HIP(hipMalloc((void **)&b.pred[i], (size_t)K * h * w * sizeof(double)));
         TMAT_HIP(hipHostMalloc((void **)&b.pred_host[i], (size_t)K * h * w * sizeof(double), hipHostMallocDefault));
@@ -108,7 +117,6 @@ static int enqueue_back(Ctx *c, int k, int slot, const TileGeom &g)
     rc = filter_edt_dev(b.pred[slot], k, b.h, b.w, 1, b.morph_ws, b.filt[slot], b.dist[slot], s);
     if (rc) return TMAT_E_HIP;
     const size_t npx = (size_t)k * b.h * b.w;
-    TMAT_HIP(hipMemcpyAsync(b.pred_host[slot], b.pred[slot], npx * sizeof(double), hipMemcpyDeviceToHost, s));
     TMAT_HIP(hipMemcpyAsync(b.filt_host[slot], b.filt[slot], npx, hipMemcpyDeviceToHost, s));
     TMAT_HIP(hipMemcpyAsync(b.dist_host[slot], b.dist[slot], npx * sizeof(double), hipMemcpyDeviceToHost, s));
     TMAT_HIP(hipMemcpyAsync(b.conv_host[slot], morph_done_flags(b.morph_ws, k, b.h, b.w), k * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -126,37 +134,6 @@ struct GraphParams {
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static bool trace_on() { static int t = -1; if (t < 0) { const char *e = getenv("TMAT_TRACE"); t = e && atoi(e) > 0; } return t; }
 
-static int analyze_host_image(const double *pred, const uint8_t *filt, const double *dist, int h, int w, const GraphParams &gp,
-                              tmat_row *row)
-{
-    const size_t nf = (size_t)gp.fh * gp.fw;
-    std::vector<float> field(nf), f255(nf);
-    const double t0 = now_s();
-    postprocess_from_filtered(pred, filt, dist, h, w, gp.fh, gp.fw, field.data());
-    const double t1 = now_s();
-    rescale255_f32(field.data(), nf, f255.data());
-    const int cap_v = (int)nf + 4, cap_e = 3 * (int)nf + 4;
-    std::vector<int32_t> V((size_t)cap_v * 2), E((size_t)cap_e * 2);
-    int nv = 0, ne = 0;
-    int rc = dmt_graph_host(f255.data(), gp.fh, gp.fw, gp.t1, gp.t2, V.data(), cap_v, E.data(), cap_e, &nv, &ne);
-    if (rc) return rc;
-    const double t2 = now_s();
-    rc = tmat_morse_stats(V.data(), nv, E.data(), ne, gp.fh, gp.fw, gp.smooth, gp.min_len, gp.max_len, gp.remove_isolated,
-                          nullptr, &row->count, &row->total_px, &row->avg_px, nullptr, 0);
-    if (trace_on())
-        fprintf(stderr, "[tmat] host image %lld: postprocess %.1f ms, dmt %.1f ms (%d verts), morse %.1f ms -> %lld branches\n",
-                (long long)row->index, (t1 - t0) * 1e3, (t2 - t1) * 1e3, nv, (now_s() - t2) * 1e3, (long long)row->count);
-    return rc;
-}
-
-struct HostJob {
-    std::vector<std::thread> threads;
-    std::atomic<int> next{0};
-    std::atomic<int> rc{0};
-    std::string err;
-    void join() { for (auto &t : threads) t.join(); threads.clear(); }
-};
-
 static int n_workers(int k)
 {
     int hw = (int)std::thread::hardware_concurrency();
@@ -166,21 +143,56 @@ static int n_workers(int k)
     return std::max(1, std::min(hw, k));
 }
 
-static void start_host_job(HostJob &job, const double *pred_host, const uint8_t *filt_host, const double *dist_host, int k, int h,
-                           int w, const GraphParams gp, tmat_row *rows)
+template <class F>
+static void parallel_images(int k, F f)
 {
-    job.next = 0;
+    std::atomic<int> next{0};
+    std::vector<std::thread> th;
     const int nt = n_workers(k);
     for (int t = 0; t < nt; t++)
-        job.threads.emplace_back([&job, pred_host, filt_host, dist_host, k, h, w, gp, rows]() {
-            for (;;) {
-                const int i = job.next.fetch_add(1);
-                if (i >= k) break;
-                const size_t o = (size_t)i * h * w;
-                int rc = analyze_host_image(pred_host + o, filt_host + o, dist_host + o, h, w, gp, &rows[i]);
-                if (rc) job.rc = rc;
-            }
-        });
+        th.emplace_back([&]() { for (;;) { const int i = next.fetch_add(1); if (i >= k) break; f(i); } });
+    for (auto &t : th) t.join();
+}
+
+// Host coordinator of one pass (runs in its own thread while the GPU works on the next pass):
+//   1. ordered medial-axis thinning per image (sequential by construction)            host threads
+//   2. EDT(~skeleton), weighting, resize, rescale on the third stream                 GPU (finish_kernels.hip)
+//   3. DMT sweeps + collect + MorseGraph statistics per image                         host threads
+struct PassJob {
+    std::thread th;
+    std::atomic<int> rc{0};
+    void join() { if (th.joinable()) th.join(); }
+};
+
+static void run_pass_host(Ctx *c, int slot, int k, const GraphParams gp, tmat_row *rows, PassJob *job)
+{
+    PassBuf &b = c->pass;
+    const int h = b.h, w = b.w;
+    const size_t per = (size_t)h * w, fper = (size_t)gp.fh * gp.fw;
+    const double t0 = now_s();
+    parallel_images(k, [&](int i) { medial_axis_thin(b.filt_host[slot] + i * per, b.dist_host[slot] + i * per, h, w, b.skel_host[slot] + i * per); });
+    const double t1 = now_s();
+    hipSetDevice(c->device);
+    hipStream_t s = c->stream3;
+    bool ok = hipMemcpyAsync(b.skel[slot], b.skel_host[slot], k * per, hipMemcpyHostToDevice, s) == hipSuccess;
+    ok = ok && finish_dev(b.pred[slot], b.dist[slot], b.skel[slot], k, h, w, gp.fh, gp.fw, b.finish_ws, b.field[slot], b.f255[slot], s) == 0;
+    ok = ok && hipMemcpyAsync(b.f255_host[slot], b.f255[slot], k * fper * sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess;
+    ok = ok && hipStreamSynchronize(s) == hipSuccess;
+    if (!ok) { job->rc = TMAT_E_HIP; return; }
+    const double t2 = now_s();
+    parallel_images(k, [&](int i) {
+        const int cap_v = (int)fper + 4, cap_e = 3 * (int)fper + 4;
+        std::vector<int32_t> V((size_t)cap_v * 2), E((size_t)cap_e * 2);
+        int nv = 0, ne = 0;
+        int rc = dmt_graph_host(b.f255_host[slot] + i * fper, gp.fh, gp.fw, gp.t1, gp.t2, V.data(), cap_v, E.data(), cap_e, &nv, &ne);
+        if (!rc)
+            rc = tmat_morse_stats(V.data(), nv, E.data(), ne, gp.fh, gp.fw, gp.smooth, gp.min_len, gp.max_len, gp.remove_isolated, nullptr,
+                                  &rows[i].count, &rows[i].total_px, &rows[i].avg_px, nullptr, 0);
+        if (rc) job->rc = rc;
+    });
+    if (trace_on())
+        fprintf(stderr, "[tmat] host pass (%d images): thinning %.1f ms, GPU finish %.1f ms, DMT + Morse %.1f ms\n", k, (t1 - t0) * 1e3,
+                (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
 }
 
 static int analyze_dev(Ctx *c, const uint16_t *imgs_dev, int n, int H, int W, double ds_ratio, int ds_width, GraphParams gp,
@@ -193,11 +205,11 @@ static int analyze_dev(Ctx *c, const uint16_t *imgs_dev, int n, int H, int W, do
     TileGeom g = make_geom(h, w, c->patch);
     if (g.tiles_per_img > c->max_patches) { set_error("analyze: image needs more patches than max_patches"); return TMAT_E_ARG; }
     const int K = std::min(n, c->max_patches / g.tiles_per_img);
-    int rc = ensure_pass_buffers(c, K, H, W, h, w);
+    int rc = ensure_pass_buffers(c, K, H, W, h, w, gp.fh, gp.fw);
     if (rc) return rc;
     for (int i = 0; i < n; i++) { rows[i].index = first_index + i; rows[i].count = 0; rows[i].total_px = 0; rows[i].avg_px = 0; }
     const int P = (n + K - 1) / K;
-    HostJob jobs[2];
+    PassJob jobs[2];
     auto cnt = [&](int p) { return std::min(K, n - p * K); };
     auto img_at = [&](int p) { return imgs_dev + (size_t)p * K * H * W; };
     rc = enqueue_front(c, img_at(0), cnt(0), 0, g);
@@ -216,8 +228,7 @@ static int analyze_dev(Ctx *c, const uint16_t *imgs_dev, int n, int H, int W, do
         if (p + 2 < P && !rc) rc = enqueue_front(c, img_at(p + 2), cnt(p + 2), slot, g);
         for (int i = 0; i < cnt(p) && !rc; i++)
             if (!c->pass.conv_host[slot][i]) { set_error("analyze: Zhang thinning did not converge within its launch budget"); rc = TMAT_E_HIP; }
-        if (!rc) start_host_job(jobs[slot], c->pass.pred_host[slot], c->pass.filt_host[slot], c->pass.dist_host[slot], cnt(p), h, w, gp,
-                                rows + (size_t)p * K);
+        if (!rc) jobs[slot].th = std::thread(run_pass_host, c, slot, cnt(p), gp, rows + (size_t)p * K, &jobs[slot]);
     }
     for (auto &j : jobs) { j.join(); if (j.rc && !rc) rc = j.rc; }
     hipStreamSynchronize(c->stream2);
@@ -242,7 +253,7 @@ int tmat_segment_batch(tmat_handle hd, const uint16_t *imgs, int n, int H, int W
     TileGeom g = make_geom(h, w, c->patch);
     if (g.tiles_per_img > c->max_patches) { set_error("tmat_segment_batch: image needs more patches than max_patches"); return TMAT_E_ARG; }
     const int K = std::min(n, c->max_patches / g.tiles_per_img);
-    int rc = ensure_pass_buffers(c, K, H, W, h, w);
+    int rc = ensure_pass_buffers(c, K, H, W, h, w, std::max(1, c->pass.fh), std::max(1, c->pass.fw));
     if (rc) return rc;
     uint16_t *dimg = nullptr;
     TMAT_HIP(hipMalloc((void **)&dimg, (size_t)K * H * W * sizeof(uint16_t)));
@@ -278,6 +289,33 @@ int tmat_filter_edt_batch(tmat_handle hd, const double *pred, int n, int hh, int
                 !hip_ok(hipStreamSynchronize(c->stream), "sync"))) rc = TMAT_E_HIP;
     for (int i = 0; i < n && !rc; i++) if (!conv[i]) { set_error("tmat_filter_edt_batch: thinning did not converge"); rc = TMAT_E_HIP; }
     hipFree(dp); hipFree(dd); hipFree(df); hipFree(ws);
+    return rc;
+}
+
+int tmat_finish_batch(tmat_handle hd, const double *pred, const double *dist, const uint8_t *skel, int n, int hh, int ww, int out_h,
+                      int out_w, float *field, float *field255)
+{
+    Ctx *c = (Ctx *)hd;
+    if (!c || !pred || !dist || !skel || !field || !field255 || n < 0 || hh < 1 || ww < 1 || out_h < 1 || out_w < 1) {
+        set_error("tmat_finish_batch: bad argument");
+        return TMAT_E_ARG;
+    }
+    if (n == 0) return TMAT_OK;
+    TMAT_HIP(hipSetDevice(c->device));
+    const size_t npx = (size_t)n * hh * ww, onpx = (size_t)n * out_h * out_w;
+    double *dp = nullptr, *dd = nullptr; uint8_t *ds = nullptr; void *ws = nullptr; float *df = nullptr, *d255 = nullptr;
+    int rc = TMAT_OK;
+    if (!hip_ok(hipMalloc((void **)&dp, npx * 8), "hipMalloc") || !hip_ok(hipMalloc((void **)&dd, npx * 8), "hipMalloc") ||
+        !hip_ok(hipMalloc((void **)&ds, npx), "hipMalloc") || !hip_ok(hipMalloc(&ws, finish_workspace_bytes(n, hh, ww, out_h, out_w)), "hipMalloc") ||
+        !hip_ok(hipMalloc((void **)&df, onpx * 4), "hipMalloc") || !hip_ok(hipMalloc((void **)&d255, onpx * 4), "hipMalloc")) rc = TMAT_E_HIP;
+    if (!rc && (!hip_ok(hipMemcpyAsync(dp, pred, npx * 8, hipMemcpyHostToDevice, c->stream), "H2D") ||
+                !hip_ok(hipMemcpyAsync(dd, dist, npx * 8, hipMemcpyHostToDevice, c->stream), "H2D") ||
+                !hip_ok(hipMemcpyAsync(ds, skel, npx, hipMemcpyHostToDevice, c->stream), "H2D"))) rc = TMAT_E_HIP;
+    if (!rc && finish_dev(dp, dd, ds, n, hh, ww, out_h, out_w, ws, df, d255, c->stream)) rc = TMAT_E_HIP;
+    if (!rc && (!hip_ok(hipMemcpyAsync(field, df, onpx * 4, hipMemcpyDeviceToHost, c->stream), "D2H") ||
+                !hip_ok(hipMemcpyAsync(field255, d255, onpx * 4, hipMemcpyDeviceToHost, c->stream), "D2H") ||
+                !hip_ok(hipStreamSynchronize(c->stream), "sync"))) rc = TMAT_E_HIP;
+    hipFree(dp); hipFree(dd); hipFree(ds); hipFree(ws); hipFree(df); hipFree(d255);
     return rc;
 }
 

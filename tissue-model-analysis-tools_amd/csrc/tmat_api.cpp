@@ -172,6 +172,7 @@ static void prof_end(Ctx *c, hipStream_t st)
 
 static bool conv(Ctx *c, ConvArgs a, hipStream_t st)
 {
+    a.zeros = c->zero_row;
     bool dom = a.ksize == 3 && a.Cout % 128 == 0;     // the conv_mfma_kernel<128,128,2,2,32,3> instantiation
     if (dom) {
         double H = (double)(a.h << a.up), W = (double)(a.w << a.up);
@@ -305,6 +306,10 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
     c->patch = patch;
     c->max_patches = max_patches > 0 ? max_patches : 400;
     if (!hip_ok(hipStreamCreate(&c->stream), "hipStreamCreate") || !build_model(c, m)) { tmat_destroy((tmat_handle)c); return TMAT_E_WEIGHTS; }
+    {   // 2048 zero floats: the row out-of-image convolution taps read
+        std::vector<float> z(2048, 0.f);
+        if (!upload(c, z, &c->zero_row)) { tmat_destroy((tmat_handle)c); return TMAT_E_HIP; }
+    }
     // activation workspace: per patch (P/2)^2 * f0 floats for buf0/buf1 and twice that for buf2/buf3
     const size_t unit = (size_t)(patch / 2) * (patch / 2) * c->f0;
     const size_t sizes[4] = {unit, unit, 2 * unit, 2 * unit};
@@ -324,7 +329,9 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
         if (!hip_ok(hipMalloc((void **)&c->dout[i], dsz * c->max_patches * sizeof(float)), "hipMalloc(dout)")) {
             tmat_destroy((tmat_handle)c); return TMAT_E_HIP;
         }
-    if (!hip_ok(hipStreamCreate(&c->stream2), "hipStreamCreate(2)")) { tmat_destroy((tmat_handle)c); return TMAT_E_HIP; }
+    if (!hip_ok(hipStreamCreate(&c->stream2), "hipStreamCreate(2)") || !hip_ok(hipStreamCreate(&c->stream3), "hipStreamCreate(3)")) {
+        tmat_destroy((tmat_handle)c); return TMAT_E_HIP;
+    }
     for (int i = 0; i < 2; i++)
         if (!hip_ok(hipEventCreateWithFlags(&c->ev_down[i], hipEventDisableTiming), "hipEventCreate")) { tmat_destroy((tmat_handle)c); return TMAT_E_HIP; }
     const size_t pp = (size_t)patch * patch * c->max_patches * sizeof(float);
@@ -374,6 +381,7 @@ void tmat_destroy(tmat_handle h)
     for (int i = 0; i < 4; i++) if (c->ubuf[i]) hipFree(c->ubuf[i]);
     for (int i = 0; i < 2; i++) { if (c->dout[i]) hipFree(c->dout[i]); if (c->ev_down[i]) hipEventDestroy(c->ev_down[i]); }
     if (c->stream2) hipStreamDestroy(c->stream2);
+    if (c->stream3) { hipStreamSynchronize(c->stream3); hipStreamDestroy(c->stream3); }
     if (c->patch_in) hipFree(c->patch_in);
     if (c->patch_out) hipFree(c->patch_out);
     if (c->scratch) hipFree(c->scratch);
@@ -390,6 +398,7 @@ int tmat_sync(tmat_handle h)
     Ctx *c = (Ctx *)h;
     if (!c) { set_error("null handle"); return TMAT_E_ARG; }
     if (c->stream2) TMAT_HIP(hipStreamSynchronize(c->stream2));
+    if (c->stream3) TMAT_HIP(hipStreamSynchronize(c->stream3));
     TMAT_HIP(hipStreamSynchronize(c->stream));
     return TMAT_OK;
 }

@@ -38,6 +38,13 @@ struct PassBuf {
     uint8_t *filt_host[2] = {nullptr, nullptr};
     double *dist_host[2] = {nullptr, nullptr};
     int *conv_host[2] = {nullptr, nullptr};
+    // finish stage (finish_kernels.hip): skeleton from the host thinning, vesselness field back to the host
+    int fh = 0, fw = 0;
+    void *finish_ws = nullptr;
+    uint8_t *skel[2] = {nullptr, nullptr};
+    uint8_t *skel_host[2] = {nullptr, nullptr};
+    float *field[2] = {nullptr, nullptr}, *f255[2] = {nullptr, nullptr};
+    float *f255_host[2] = {nullptr, nullptr};
     hipEvent_t done[2] = {nullptr, nullptr};
 };
 
@@ -50,12 +57,14 @@ struct Ctx {
     std::vector<DownBlock> down;
     std::vector<UpBlock> up;
     float *final_w = nullptr;
+    float *zero_row = nullptr;
     float final_b = 0.f;
     std::vector<void *> owned;              // weight allocations
     float *buf[4] = {nullptr, nullptr, nullptr, nullptr};    // down-path ping-pong activations
     float *ubuf[4] = {nullptr, nullptr, nullptr, nullptr};   // up-path activations
     float *dout[2] = {nullptr, nullptr};                     // down-path output (P/16)^2 x f_deep, double-buffered
     hipStream_t stream2 = nullptr;                           // second stream: down path of pass p+1 overlaps up path of pass p
+    hipStream_t stream3 = nullptr;                           // third stream: finish stage of pass p-1 (after the host thinning)
     hipEvent_t ev_down[2] = {nullptr, nullptr};
     float *patch_in = nullptr, *patch_out = nullptr;
     void *scratch = nullptr;
@@ -67,13 +76,16 @@ struct Ctx {
     {
         PassBuf &b = pass;
         void *dev[] = {b.xi, b.yi, b.xc, b.yc, b.tmp, b.x, b.small, b.mn, b.mx, b.pred[0], b.pred[1], b.morph_ws,
-                       b.filt[0], b.filt[1], b.dist[0], b.dist[1]};
+                       b.filt[0], b.filt[1], b.dist[0], b.dist[1], b.finish_ws, b.skel[0], b.skel[1], b.field[0], b.field[1],
+                       b.f255[0], b.f255[1]};
         for (void *p : dev) if (p) hipFree(p);
         for (int i = 0; i < 2; i++) {
             if (b.pred_host[i]) hipHostFree(b.pred_host[i]);
             if (b.filt_host[i]) hipHostFree(b.filt_host[i]);
             if (b.dist_host[i]) hipHostFree(b.dist_host[i]);
             if (b.conv_host[i]) hipHostFree(b.conv_host[i]);
+            if (b.skel_host[i]) hipHostFree(b.skel_host[i]);
+            if (b.f255_host[i]) hipHostFree(b.f255_host[i]);
             if (b.done[i]) hipEventDestroy(b.done[i]);
         }
         pass = PassBuf();

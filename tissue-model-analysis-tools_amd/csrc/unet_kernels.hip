@@ -305,17 +305,9 @@ bool launch_conv(const ConvArgs &a, hipStream_t s)
     }
     const int M = (int)Mll;
     static const int stagger = [] { const char *e = getenv("TMAT_STAGGER"); return e ? atoi(e) : 0; }();
-    static float *zeros = nullptr;        // 2048 zero floats shared by every launch (out-of-image taps read it)
-    if (!zeros) {
-        if (hipMalloc((void **)&zeros, 2048 * sizeof(float)) != hipSuccess || hipMemset(zeros, 0, 2048 * sizeof(float)) != hipSuccess) {
-            set_error("launch_conv: cannot allocate the zero row");
-            return false;
-        }
-    }
-    if (a.Cin > 2048) { set_error("launch_conv: Cin > 2048"); return false; }
+    if (!a.zeros || a.Cin > 2048) { set_error("launch_conv: missing zero row or Cin > 2048"); return false; }
     ConvArgs b = a;
     b.stagger = stagger;
-    b.zeros = zeros;
     if (a.Cout % 128 == 0)
         launch_conv_cfg<128, 128, 2, 2, 32>(b, M, Ho, Wo, s);
     else

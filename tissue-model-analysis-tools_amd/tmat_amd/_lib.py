@@ -47,6 +47,7 @@ def lib():
     L.tmat_segment_batch.argtypes = [vp, vp, i, i, i, C.c_double, vp]
     L.tmat_postprocess_batch.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.tmat_filter_edt_batch.argtypes = [vp, vp, i, i, i, vp, vp]
+    L.tmat_finish_batch.argtypes = [vp, vp, vp, vp, i, i, i, i, i, vp, vp]
     L.tmat_dmt_graph.argtypes = [vp, vp, i, i, f, f, vp, i, vp, i, C.POINTER(i), C.POINTER(i)]
     L.tmat_morse_stats.argtypes = [vp, i, vp, i, i, i, i, i, i, i, vp, C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                    C.POINTER(C.c_double), vp, i]
@@ -67,7 +68,7 @@ def lib():
 
 EXPORTS = [
     "tmat_last_error", "tmat_version", "tmat_create", "tmat_destroy", "tmat_sync", "tmat_unet_predict",
-    "tmat_predict_smooth", "tmat_segment_batch", "tmat_postprocess_batch", "tmat_filter_edt_batch", "tmat_dmt_graph", "tmat_morse_stats",
+    "tmat_predict_smooth", "tmat_segment_batch", "tmat_postprocess_batch", "tmat_filter_edt_batch", "tmat_finish_batch", "tmat_dmt_graph", "tmat_morse_stats",
     "tmat_analyze_batch_dev", "tmat_analyze_batch", "tmat_dev_alloc", "tmat_dev_free", "tmat_dev_upload",
     "tmat_prof_enable", "tmat_prof_read", "tmat_host_lanczos4_u16", "tmat_host_rescale01_u16",
     "tmat_host_rescale255_f32", "tmat_host_filter_mask", "tmat_host_skeletonize", "tmat_host_medial_axis",
@@ -135,6 +136,18 @@ class Handle:
         check(lib().tmat_filter_edt_batch(self._h, ptr(pred), pred.shape[0], pred.shape[1], pred.shape[2], ptr(filt), ptr(dist)),
               "tmat_filter_edt_batch")
         return filt.astype(bool), dist
+
+    def finish(self, pred, dist, skel, out_shape):
+        """GPU: EDT(~skel), centre-line weighting, anti-aliased resize, rescale -> (field f32, field255 f32)"""
+        pred = np.ascontiguousarray(pred, np.float64)
+        dist = np.ascontiguousarray(dist, np.float64)
+        skel = np.ascontiguousarray(np.asarray(skel) != 0, np.uint8)
+        n = pred.shape[0]
+        f = np.empty((n,) + tuple(out_shape), np.float32)
+        f255 = np.empty_like(f)
+        check(lib().tmat_finish_batch(self._h, ptr(pred), ptr(dist), ptr(skel), n, pred.shape[1], pred.shape[2], out_shape[0],
+                                      out_shape[1], ptr(f), ptr(f255)), "tmat_finish_batch")
+        return f, f255
 
     def prof_enable(self, on=True):
         check(lib().tmat_prof_enable(self._h, int(on)), "tmat_prof_enable")
