@@ -85,9 +85,37 @@ def convt_as_conv(k):
     return _f32(k[::-1, ::-1].transpose(0, 1, 3, 2))
 
 
+def subpixel_weights(Wc):
+    """3x3 conv taps (3, 3, Cin, Cout) -> (4, 4, Cin, Cout): the taps of a 3x3 convolution over a 2x nearest-upsampled
+    tensor that land on the same stored pixel, summed per output parity class (py, px).  Full-resolution offset d of an
+    output pixel of parity p reads stored offset (p + d) >> 1, i.e. slot a = ((p + d) >> 1) - (p - 1).  f32 adds from
+    +0.0 in (ky, kx) order -- the same order as csrc/tmat_api.cpp:subpixel_weights."""
+    Wc = _f32(Wc)
+    out = np.zeros((2, 2, 2, 2) + Wc.shape[2:], np.float32)
+    for py in range(2):
+        for px in range(2):
+            for ky in range(3):
+                for kx in range(3):
+                    a = ((py + ky - 1) >> 1) - (py - 1)
+                    b = ((px + kx - 1) >> 1) - (px - 1)
+                    out[py, px, a, b] = out[py, px, a, b] + Wc[ky, kx]
+    return out.reshape((4, 4) + Wc.shape[2:])
+
+
 # ----------------------------------------------------------------------------------------
 # exact path
 # ----------------------------------------------------------------------------------------
+def _conv_subpixel(S, Wc3, relu_in, scale, shift, relu_out):
+    L = lib()
+    N, h, w, cin = S.shape
+    cout = Wc3.shape[-1]
+    out = np.empty((N, 2 * h, 2 * w, cout), np.float32)
+    Ws = _f32(subpixel_weights(Wc3))
+    rc = L.orc_conv_subpixel(_p(S), N, h, w, cin, relu_in, _p(Ws), cout, _p(scale), _p(shift), relu_out, _p(out))
+    assert rc == 0, rc
+    return out
+
+
 def _conv(S, Wc, ksize, stride, up, relu_in, scale, shift, resid, rs, relu_out):
     L = lib()
     N, h, w, cin = S.shape
@@ -110,9 +138,11 @@ def _dw(S, Wd, relu_in):
     return out
 
 
-def forward_exact(w, x, taps=None):
+def forward_exact(w, x, taps=None, subpixel=True):
     """x: (N, P, P) float32 -> (N, P, P) float32 sigmoid output.  `taps` (dict) collects
-    intermediate tensors by name when given."""
+    intermediate tensors by name when given.  `subpixel=False` evaluates the first transposed convolution of the
+    up blocks as the as-written 9-tap chain over the upsampled tensor instead of the 4-tap sub-pixel form (the two
+    differ by f32 rounding of the pre-summed taps only; tests bound the difference)."""
     L = lib()
     x = _f32(x)
     N, P, _ = x.shape
@@ -145,7 +175,10 @@ def forward_exact(w, x, taps=None):
     while f"up{j}.ct1.w" in w:
         p = f"up{j}"
         sc, sh = fold_bn(w[f"{p}.bn1"], w[f"{p}.ct1.b"])
-        t1 = _conv(S, convt_as_conv(w[f"{p}.ct1.w"]), 3, 1, up, 1, sc, sh, None, 0, 1)
+        if up and subpixel:
+            t1 = _conv_subpixel(S, convt_as_conv(w[f"{p}.ct1.w"]), 1, sc, sh, 1)
+        else:
+            t1 = _conv(S, convt_as_conv(w[f"{p}.ct1.w"]), 3, 1, up, 1, sc, sh, None, 0, 1)
         rr = _conv(S, w[f"{p}.res.w"], 1, 1, 0, 0, None, _f32(w[f"{p}.res.b"]), None, 0, 0)
         sc, sh = fold_bn(w[f"{p}.bn2"], w[f"{p}.ct2.b"])
         S = _conv(t1, convt_as_conv(w[f"{p}.ct2.w"]), 3, 1, 0, 0, sc, sh, rr, up, 0)

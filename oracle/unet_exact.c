@@ -174,6 +174,56 @@ int orc_conv(const float *S, int N, int h, int w, int Cin, int up, int relu_in, 
     return 0;
 }
 
+/*
+ * 3x3 convolution over the 2x nearest-upsampled stored tensor, in sub-pixel form (first transposed convolution
+ * of up blocks 2.. : models.py:150-152 applied to the UpSampling2D output of models.py:158-163).  Output pixel
+ * (2i + py, 2j + px) only sees the stored pixels (i + py - 1 + a, j + px - 1 + b), a, b in {0, 1}; the 3x3 taps that
+ * land on the same stored pixel are pre-summed (unet.py:subpixel_weights, f32 adds in (ky, kx) order), which is what
+ * csrc/unet_kernels.hip (KS == 2) multiplies.  Wsub layout [4 classes = py * 2 + px][4 taps = a * 2 + b][Cin][Cout];
+ * the chain per class follows conv_block's K order with 4 taps.  Same epilogue as orc_conv (no residual).
+ */
+int orc_conv_subpixel(const float *S, int N, int h, int w, int Cin, int relu_in, const float *Wsub, int Cout,
+                      const float *scale, const float *shift, int relu_out, float *out)
+{
+    float *P = make_padded(S, N, h, w, Cin, 0, relu_in, 1);
+    if (!P) return -2;
+    size_t Hp = h + 2, Wp = w + 2;
+    static const float zeros[2048] = {0};
+    if (Cin > 2048) { free(P); return -3; }
+    const int Ho = 2 * h, Wo = 2 * w;
+#pragma omp parallel for collapse(2) schedule(dynamic, 4)
+    for (int n = 0; n < N; n++)
+        for (int y = 0; y < Ho; y++) {
+            float acc[XB][OB];
+            const float *ip[4 * XB];
+            const int i0 = y >> 1, py = y & 1;
+            for (int px = 0; px < 2; px++) {
+                const float *Wc = Wsub + (size_t)(py * 2 + px) * 4 * Cin * Cout;
+                for (int j0 = 0; j0 < w; j0 += XB) {
+                    int xb = w - j0 < XB ? w - j0 : XB;
+                    for (int t = 0; t < 4; t++)
+                        for (int i = 0; i < XB; i++)
+                            ip[t * XB + i] = i < xb ? P + (((size_t)n * Hp + i0 + py + (t >> 1)) * Wp + j0 + i + px + (t & 1)) * Cin
+                                                    : zeros;
+                    for (int o0 = 0; o0 < Cout; o0 += OB) {
+                        int ob = Cout - o0 < OB ? Cout - o0 : OB;
+                        conv_block(ip, 4, Cin, Wc, Cout, o0, ob, acc);
+                        for (int i = 0; i < xb; i++) {
+                            float *op = out + (((size_t)n * Ho + y) * Wo + 2 * (j0 + i) + px) * Cout + o0;
+                            for (int o = 0; o < ob; o++) {
+                                float v = scale ? __builtin_fmaf(acc[i][o], scale[o0 + o], shift[o0 + o]) : acc[i][o] + shift[o0 + o];
+                                if (relu_out) v = relu_f(v);
+                                op[o] = v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    free(P);
+    return 0;
+}
+
 /* depthwise 3x3, zero pad 1, relu on load optional; Wd layout [9][C]; chain over taps in order */
 CLONES int orc_dwconv(const float *S, int N, int H, int W, int C, int relu_in, const float *Wd, float *out)
 {

@@ -64,6 +64,28 @@ def test_exact_unet_matches_torch_restatement_small():
     np.testing.assert_allclose(a, b, rtol=0, atol=2e-5)
 
 
+def test_subpixel_form_equals_as_written_taps():
+    """The 4-tap sub-pixel form of the first transposed convolution of up blocks 2.. is the as-written 9-tap
+    convolution over the upsampled tensor up to f32 rounding of the pre-summed taps (and exactly equal when the
+    taps are small integers, where no sum rounds)."""
+    w = _dense_random_weights((8, 16, 32, 64), 4)
+    x = np.random.RandomState(5).uniform(0, 1, (2, 32, 32)).astype(np.float32)
+    ta, tb = {}, {}
+    a = ou.forward_exact(w, x, taps=ta, subpixel=True)
+    b = ou.forward_exact(w, x, taps=tb, subpixel=False)
+    np.testing.assert_allclose(a, b, rtol=0, atol=1e-5)
+    for k in ta:
+        np.testing.assert_allclose(ta[k], tb[k], rtol=0, atol=2e-5 * max(1.0, float(np.abs(tb[k]).max())))
+    # exact case: integer-valued taps and inputs (every product and sum is exact in f32)
+    rs = np.random.RandomState(6)
+    W9 = rs.randint(-3, 4, (3, 3, 32, 64)).astype(np.float32)
+    S = rs.randint(-4, 5, (2, 5, 7, 32)).astype(np.float32)
+    one, zero = np.ones(64, np.float32), np.zeros(64, np.float32)
+    full = ou._conv(S, W9, 3, 1, 1, 1, one, zero, None, 0, 0)
+    sub = ou._conv_subpixel(S, W9, 1, one, zero, 0)
+    assert np.array_equal(full, sub)
+
+
 def test_exact_unet_full_size_one_patch():
     w = synth.synth_weights(0)
     x = np.random.RandomState(3).uniform(0, 1, (1, 320, 320)).astype(np.float32)

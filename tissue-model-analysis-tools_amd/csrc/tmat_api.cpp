@@ -82,6 +82,25 @@ static std::vector<float> convt_as_conv(const Tensor &k)
     return w;
 }
 
+// Sub-pixel form of a 3x3 convolution over a 2x nearest-upsampled tensor (unet_kernels.hip, KS == 2): per output
+// parity class (py, px) the taps that land on the same stored pixel are summed -- f32 adds from +0.0 in (ky, kx)
+// order, as oracle/unet.py:subpixel_weights does.  [9][I][O] -> [4 classes][4 slots][I][O]
+static std::vector<float> subpixel_weights(const std::vector<float> &w9, int I, int O)
+{
+    const size_t IO = (size_t)I * O;
+    std::vector<float> w(16 * IO, 0.0f);
+    for (int py = 0; py < 2; py++)
+        for (int px = 0; px < 2; px++)
+            for (int ky = 0; ky < 3; ky++)
+                for (int kx = 0; kx < 3; kx++) {
+                    const int a = ((py + ky - 1) >> 1) - (py - 1), b = ((px + kx - 1) >> 1) - (px - 1);
+                    float *d = &w[((size_t)(py * 2 + px) * 4 + a * 2 + b) * IO];
+                    const float *s = &w9[(size_t)(ky * 3 + kx) * IO];
+                    for (size_t i = 0; i < IO; i++) d[i] = d[i] + s[i];
+                }
+    return w;
+}
+
 static bool need(const std::map<std::string, Tensor> &m, const std::string &k, Tensor &t)
 {
     auto it = m.find(k);
@@ -132,7 +151,10 @@ static bool build_model(Ctx *c, const std::map<std::string, Tensor> &m)
             if (!need(m, sp + ".w", w) || !need(m, sp + ".b", b) || !need(m, p + (s ? ".bn2" : ".bn1"), bn)) return false;
             if (w.shape.size() != 4 || w.shape[0] != 3 || w.shape[1] != 3) { set_error("weights: ConvT must be 3x3"); return false; }
             fold_bn(bn, b, sc, sh);
-            if (!upload(c, convt_as_conv(w), &u.ct[s]) || !upload(c, sc, &u.scale[s]) || !upload(c, sh, &u.shift[s])) return false;
+            const std::vector<float> w9 = convt_as_conv(w);
+            if (!upload(c, w9, &u.ct[s]) || !upload(c, sc, &u.scale[s]) || !upload(c, sh, &u.shift[s])) return false;
+            // blocks after the first read a 2x nearest-upsampled tensor in their first convolution: sub-pixel form
+            if (s == 0 && j > 0 && !upload(c, subpixel_weights(w9, w.shape[3], w.shape[2]), &u.ct_sub)) return false;
             u.cout = w.shape[2];
         }
         if (!need(m, p + ".res.w", w) || !need(m, p + ".res.b", rb)) return false;
@@ -228,7 +250,9 @@ int unet_up_dev(Ctx *c, const float *dout, int n, float *Y, hipStream_t s)
         float *so = c->ubuf[so_idx];
         ConvArgs a{};
         a.in = S; a.N = n; a.h = Hs; a.w = Hs; a.Cin = u.cin; a.up = up; a.relu_in = 1; a.ksize = 3; a.stride = 1;
-        a.W = u.ct[0]; a.Cout = u.cout; a.scale = u.scale[0]; a.shift = u.shift[0]; a.relu_out = 1; a.out = t1;
+        a.W = u.ct[0];
+        if (up) { a.up = 0; a.ksize = 2; a.W = u.ct_sub; }      // 4 taps per output parity class instead of 9
+        a.Cout = u.cout; a.scale = u.scale[0]; a.shift = u.shift[0]; a.relu_out = 1; a.out = t1;
         if (!conv(c, a, s)) return TMAT_E_ARG;
         ConvArgs r{};
         r.in = S; r.N = n; r.h = Hs; r.w = Hs; r.Cin = u.cin; r.ksize = 1; r.stride = 1; r.W = u.res_w; r.Cout = u.cout;

@@ -16,6 +16,7 @@ struct DownBlock {
 struct UpBlock {
     int cin = 0, cout = 0;
     float *ct[2] = {nullptr, nullptr};      // conv-form taps [9][Cin][Cout]
+    float *ct_sub = nullptr;                // first conv in sub-pixel form [4][4][Cin][Cout] (blocks after the first)
     float *scale[2] = {nullptr, nullptr}, *shift[2] = {nullptr, nullptr};
     float *res_w = nullptr, *res_b = nullptr;
 };

@@ -17,9 +17,9 @@ struct ConvArgs {
     int N, h, w, Cin;
     int up;               // logical input = nearest-upsample^up of the stored tensor
     int relu_in;          // relu applied on load
-    int ksize;            // 1 or 3
+    int ksize;            // 1 or 3; 2 = sub-pixel form of a 3x3 over the 2x nearest-upsampled stored tensor (out is 2h x 2w)
     int stride;           // 1, or 2 with ksize 1 (TF SAME 1x1 s2 samples even indices)
-    const float *W;       // [ksize*ksize][Cin][Cout]
+    const float *W;       // [ksize*ksize][Cin][Cout]; ksize 2: [4 parity classes][4][Cin][Cout]
     int Cout;
     const float *scale;   // nullable: v = scale ? fmaf(acc, scale, shift) : acc + shift
     const float *shift;

@@ -30,8 +30,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int BM, int BN, int WM, int WN, int KC, int KS>
 __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_mfma_kernel(ConvArgs a, int M, int Ho, int Wo, int nMt, int nNt)
 {
-    // KS (1 or 3) is a template parameter so that the 3x3 and the pointwise instantiations are distinct kernels
+    // KS (1, 2 or 3) is a template parameter so that the 3x3 and the pointwise instantiations are distinct kernels
     // (distinct names in rocprofv3 traces: the 3x3 <128,128,2,2,32,3> instantiation is the dominant kernel).
+    // KS == 2 is the sub-pixel form of a 3x3 convolution over a 2x nearest-upsampled input: output pixel
+    // (2i + py, 2j + px) only sees the 2x2 stored pixels (i + py - 1 + {0,1}, j + px - 1 + {0,1}), with the 3x3 taps that
+    // fall on the same stored pixel pre-summed per parity class (weights [class][tap][Cin][Cout], class = blockIdx.y,
+    // M enumerates the stored pixels).  4/9 of the multiply-adds of the as-written form.
     static_assert(WM * WN == 4, "4 waves");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int LDA = BM + 1;
@@ -71,6 +75,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_mfma_kernel(Conv
     const int wm = wave / WN, wn = wave % WN;
 
     const int H = a.h << a.up, W = a.w << a.up;
+    const int spy = KS == 2 ? (int)(blockIdx.y >> 1) : 0, spx = KS == 2 ? (int)(blockIdx.y & 1) : 0;
     constexpr int taps = KS * KS;
     const int cchunks = a.Cin / KC;
     const int nchunks = taps * cchunks;
@@ -98,6 +103,12 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_mfma_kernel(Conv
                     const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
                     if (yy >= 0 && yy < H && xx >= 0 && xx < W) msk |= 1u << tp;
                 }
+            } else if (KS == 2) {
+#pragma unroll
+                for (int tp = 0; tp < 4; tp++) {
+                    const int yy = y + spy - 1 + (tp >> 1), xx = x + spx - 1 + (tp & 1);
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) msk |= 1u << tp;
+                }
             } else msk = 1u;
         }
         pm[i] = msk | ((unsigned)(y & 1) << 9) | ((unsigned)(x & 1) << 10);
@@ -118,7 +129,7 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_mfma_kernel(Conv
     static_assert(NPB == 4 || NPB == 2 || NPB == 1, "B passes");
     const float *ab0 = a.zeros, *ab1 = a.zeros, *ab2 = a.zeros, *ab3 = a.zeros, *ab4 = a.zeros, *ab5 = a.zeros, *ab6 = a.zeros,
                 *ab7 = a.zeros;
-    const float *wbase = a.W + n0 + bcol + (size_t)brow * a.Cout;
+    const float *wbase = a.W + (KS == 2 ? (size_t)blockIdx.y * 4 * a.Cin * a.Cout : (size_t)0) + n0 + bcol + (size_t)brow * a.Cout;
     // chunk order: 32-channel block major, then tap, then (KC = 16 only) the two halves of the block
     constexpr int HPB = 32 / KC;            // chunks per (block, tap)
     int ld_cb = 0, ld_tap = 0, ld_half = 0, ld_cc = 0;
@@ -134,8 +145,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_mfma_kernel(Conv
 #define TMAT_LOAD_CHUNK(S)                                                             \
     {                                                                                  \
         if (ld_half == 0 && ld_cc < nchunks) {                                         \
-            const int dy = KS == 3 ? ld_tap / 3 - 1 : 0;                               \
-            const int dx = KS == 3 ? ld_tap % 3 - 1 : 0;                               \
+            const int dy = KS == 3 ? ld_tap / 3 - 1 : KS == 2 ? spy - 1 + (ld_tap >> 1) : 0; \
+            const int dx = KS == 3 ? ld_tap % 3 - 1 : KS == 2 ? spx - 1 + (ld_tap & 1) : 0;  \
             TMAT_BASE(0, ab0) TMAT_BASE(1, ab1) TMAT_BASE(2, ab2) TMAT_BASE(3, ab3)    \
             TMAT_BASE(4, ab4) TMAT_BASE(5, ab5) TMAT_BASE(6, ab6) TMAT_BASE(7, ab7)    \
         }                                                                              \
@@ -275,7 +286,14 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_mfma_kernel(Conv
                     v.x = v.x + rv.x; v.y = v.y + rv.y; v.z = v.z + rv.z; v.w = v.w + rv.w;
                 }
                 if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                *reinterpret_cast<float4 *>(a.out + (size_t)m * a.Cout + co) = v;
+                size_t oidx = (size_t)m;
+                if (KS == 2) {      // scatter to the parity class's pixels of the (2 Ho, 2 Wo) output
+                    const int n = m / (Ho * Wo);
+                    const int rr = m - n * (Ho * Wo);
+                    const int y = rr / Wo, x = rr - y * Wo;
+                    oidx = ((size_t)n * 2 * Ho + 2 * y + spy) * (2 * Wo) + 2 * x + spx;
+                }
+                *reinterpret_cast<float4 *>(a.out + oidx * a.Cout + co) = v;
             }
             if (pass + 1 < NPASS) __syncthreads();
         }
@@ -289,6 +307,8 @@ static void launch_conv_cfg(const ConvArgs &a, int M, int Ho, int Wo, hipStream_
     int grid = ((nMt + 7) / 8) * 8 * nNt;
     if (a.ksize == 3)
         hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KC, 3>), dim3(grid), dim3(256), 0, s, a, M, Ho, Wo, nMt, nNt);
+    else if (a.ksize == 2)
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KC, 2>), dim3(grid, 4), dim3(256), 0, s, a, M, Ho, Wo, nMt, nNt);
     else
         hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KC, 1>), dim3(grid), dim3(256), 0, s, a, M, Ho, Wo, nMt, nNt);
 }
@@ -298,7 +318,8 @@ bool launch_conv(const ConvArgs &a, hipStream_t s)
     const int H = a.h << a.up, W = a.w << a.up;
     const int Ho = H / a.stride, Wo = W / a.stride;
     const long long Mll = (long long)a.N * Ho * Wo;
-    if (!((a.ksize == 3 && a.stride == 1) || (a.ksize == 1 && (a.stride == 1 || a.stride == 2))) || a.Cin % 32 ||
+    if (!((a.ksize == 3 && a.stride == 1) || (a.ksize == 2 && a.stride == 1 && a.up == 0 && !a.resid) ||
+          (a.ksize == 1 && (a.stride == 1 || a.stride == 2))) || a.Cin % 32 ||
         a.Cout % 64 || ((a.ksize * a.ksize * (a.Cin / (a.Cout % 128 == 0 ? 32 : 16))) & 1) || Mll <= 0 || Mll > 0x7fffffffLL / 2 || (a.resid && a.rs && ((Ho | Wo) & 1))) {
         set_error("launch_conv: unsupported shape");
         return false;
