@@ -86,12 +86,16 @@ CLONES static void conv_block(const float *const *ip /*[taps][XB] row ptrs*/, in
     for (int i = 0; i < XB; i++)
         for (int o = 0; o < OB; o++) acc[i][o] = 0.0f;
     /* K order of the chain (shared with csrc/unet_kernels.hip): input channels in blocks of CB = 32; inside a
-       block tap-major (ky, kx), then channel ascending.  (Block-major order keeps the 3x3 window of a channel
-       block hot in cache / L2 across its 9 taps.) */
+       block tap-major (ky, kx); inside a (block, tap) the channels of every group of 8 in the order 0,4,1,5,2,6,3,7
+       (a lane of the MFMA kernel reads 4 consecutive channels with one ds_read_b128, lanes 0-31 the lower and lanes
+       32-63 the upper half of the group, and each v_mfma_f32_32x32x2_f32 consumes one channel of either half).
+       Block-major order keeps the 3x3 window of a channel block hot in L2 across its taps. */
     for (int cb = 0; cb < Cin; cb += CB)
     for (int t = 0; t < taps; t++) {
         const float *w = Wc + (size_t)t * Cin * Cout + o0;
-        for (int c = cb; c < cb + CB && c < Cin; c++) {
+        for (int q = 0; q < CB; q++) {
+            const int c = cb + (q & ~7) + ((q & 1) << 2) + ((q & 7) >> 1);
+            if (c >= Cin) continue;
             const float *wr = w + (size_t)c * Cout;
             if (ob == OB) {
                 for (int i = 0; i < XB; i++) {

@@ -101,6 +101,16 @@ static std::vector<float> subpixel_weights(const std::vector<float> &w9, int I, 
     return w;
 }
 
+// [taps][I][O] -> [taps][O][I]: the MFMA convolution reads both operands k-contiguous (unet_kernels.hip)
+static std::vector<float> k_contiguous(const float *w, int taps, int I, int O)
+{
+    std::vector<float> r((size_t)taps * I * O);
+    for (int t = 0; t < taps; t++)
+        for (int i = 0; i < I; i++)
+            for (int o = 0; o < O; o++) r[((size_t)t * O + o) * I + i] = w[((size_t)t * I + i) * O + o];
+    return r;
+}
+
 static bool need(const std::map<std::string, Tensor> &m, const std::string &k, Tensor &t)
 {
     auto it = m.find(k);
@@ -131,12 +141,12 @@ static bool build_model(Ctx *c, const std::map<std::string, Tensor> &m)
                 !need(m, p + (s ? ".bn2" : ".bn1"), bn)) return false;
             fold_bn(bn, b, sc, sh);
             if (!upload(c, std::vector<float>(dw.data, dw.data + dw.count), &d.dw[s]) ||
-                !upload(c, std::vector<float>(pw.data, pw.data + pw.count), &d.pw[s]) || !upload(c, sc, &d.scale[s]) ||
+                !upload(c, k_contiguous(pw.data, 1, pw.shape[0], pw.shape[1]), &d.pw[s]) || !upload(c, sc, &d.scale[s]) ||
                 !upload(c, sh, &d.shift[s])) return false;
             d.cout = pw.shape[1];
         }
         if (!need(m, p + ".res.w", w) || !need(m, p + ".res.b", rb)) return false;
-        if (!upload(c, std::vector<float>(w.data, w.data + w.count), &d.res_w) ||
+        if (!upload(c, k_contiguous(w.data, 1, d.cin, d.cout), &d.res_w) ||
             !upload(c, std::vector<float>(rb.data, rb.data + rb.count), &d.res_b)) return false;
         c->down.push_back(d);
         cin = d.cout;
@@ -152,13 +162,14 @@ static bool build_model(Ctx *c, const std::map<std::string, Tensor> &m)
             if (w.shape.size() != 4 || w.shape[0] != 3 || w.shape[1] != 3) { set_error("weights: ConvT must be 3x3"); return false; }
             fold_bn(bn, b, sc, sh);
             const std::vector<float> w9 = convt_as_conv(w);
-            if (!upload(c, w9, &u.ct[s]) || !upload(c, sc, &u.scale[s]) || !upload(c, sh, &u.shift[s])) return false;
+            const int I = w.shape[3], O = w.shape[2];
+            if (!upload(c, k_contiguous(w9.data(), 9, I, O), &u.ct[s]) || !upload(c, sc, &u.scale[s]) || !upload(c, sh, &u.shift[s])) return false;
             // blocks after the first read a 2x nearest-upsampled tensor in their first convolution: sub-pixel form
-            if (s == 0 && j > 0 && !upload(c, subpixel_weights(w9, w.shape[3], w.shape[2]), &u.ct_sub)) return false;
+            if (s == 0 && j > 0 && !upload(c, k_contiguous(subpixel_weights(w9, I, O).data(), 16, I, O), &u.ct_sub)) return false;
             u.cout = w.shape[2];
         }
         if (!need(m, p + ".res.w", w) || !need(m, p + ".res.b", rb)) return false;
-        if (!upload(c, std::vector<float>(w.data, w.data + w.count), &u.res_w) ||
+        if (!upload(c, k_contiguous(w.data, 1, u.cin, u.cout), &u.res_w) ||
             !upload(c, std::vector<float>(rb.data, rb.data + rb.count), &u.res_b)) return false;
         c->up.push_back(u);
         cin = u.cout;

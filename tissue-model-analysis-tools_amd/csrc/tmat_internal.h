@@ -15,11 +15,11 @@ bool hip_ok(hipError_t e, const char *what);
 struct ConvArgs {
     const float *in;      // stored tensor (N, h, w, Cin)
     int N, h, w, Cin;
-    int up;               // logical input = nearest-upsample^up of the stored tensor
+    int up;               // must be 0 (upsampled inputs go through the sub-pixel form, ksize 2)
     int relu_in;          // relu applied on load
     int ksize;            // 1 or 3; 2 = sub-pixel form of a 3x3 over the 2x nearest-upsampled stored tensor (out is 2h x 2w)
     int stride;           // 1, or 2 with ksize 1 (TF SAME 1x1 s2 samples even indices)
-    const float *W;       // [ksize*ksize][Cin][Cout]; ksize 2: [4 parity classes][4][Cin][Cout]
+    const float *W;       // [ksize*ksize][Cout][Cin] (k contiguous); ksize 2: [4 parity classes][4][Cout][Cin]
     int Cout;
     const float *scale;   // nullable: v = scale ? fmaf(acc, scale, shift) : acc + shift
     const float *shift;
@@ -27,8 +27,7 @@ struct ConvArgs {
     int rs;
     int relu_out;
     float *out;           // (N, H/stride, W/stride, Cout), H = h << up
-    const float *zeros;   // >= Cin zero floats: source of out-of-image taps (set by launch_conv)
-    int stagger;          // start delay (x 512 cycles) of every second generation of blocks (set by launch_conv)
+    const float *zeros;   // >= Cin zero floats: source of out-of-image taps (set by tmat_api.cpp:conv)
 };
 // returns false (and sets the error) on unsupported shapes
 bool launch_conv(const ConvArgs &a, hipStream_t s);

@@ -5,7 +5,8 @@
 //
 // Arithmetic contract (shared with oracle/unet_exact.c, compared bit-exactly):
 //   every contraction is a chain acc = fmaf(a[k], w[k], acc); for the MFMA convolutions k walks the
-//   input channels in blocks of 32, inside a block tap-major (ky, kx), then channel ascending
+//   input channels in blocks of 32, inside a block tap-major (ky, kx), then the block's channels in the order
+//   0,4,1,5,2,6,3,7, 8,12,9,13,... (the order ds_read_b128 fragments feed the MFMA; see conv_mfma_kernel)
 //   (depthwise / stem / final: tap-major, channel ascending); v_mfma_f32_32x32x2_f32 performs exactly
 //   such a chain (one rounding per product, k ascending), so the dense 3x3 / 1x1 contractions run on
 //   the matrix cores at full f32 precision.  Epilogues: v = fmaf(acc, scale, shift) (folded BN) or acc + bias,
@@ -20,50 +21,51 @@ namespace tmat {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------
-// implicit-GEMM convolution on MFMA:  C[m][co] = sum_{tap, ci} A(m, tap, ci) * W[tap][ci][co]
-//   m = flattened (n, y, x) output pixel.  A is gathered on the fly (zero padding, optional
-//   nearest-upsample of the stored input, optional ReLU on load) -> LDS (k-major, padded),
-//   W chunk -> LDS.  256 threads = 4 waves arranged WM x WN, each wave owns
-//   (BM/WM) x (BN/WN) outputs as TM x TN tiles of 32x32 (16 accumulator VGPRs each).
-//   Register-prefetch double buffering: one barrier per K chunk.
+// implicit-GEMM convolution on MFMA:  C[m][co] = sum_{cb, tap, k in block} A(m, tap, cb*32+k) * W[tap][co][cb*32+k]
+//   m = flattened (n, y, x) output pixel.  Both operands live in LDS as [row][32 channels] images (128-byte rows,
+//   k contiguous -- the NHWC layout of the activations and the [tap][Cout][Cin] layout of the weights), filled by
+//   LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR staging, no ds_write pass).  The 16-byte slot p of row r holds the
+//   channel group p ^ (r & 7): the DMA destination is lane-linear, so the swizzle is applied to the per-lane SOURCE
+//   address, and to the slot index on the read side; fragments are read with ds_read_b128, conflict-free.
+//   One K chunk = one (32-channel block, tap); out-of-image taps are out-of-range buffer offsets (zeros).  Two LDS stages: the DMA of chunk
+//   c+1 is issued before the MFMAs of chunk c and retired (vmcnt(0)) at the single barrier that ends chunk c.
+//   256 threads = 4 waves arranged WM x WN, each wave owns (BM/WM) x (BN/WN) outputs as TM x TN tiles of 32x32.
+//   A lane's b128 fragment holds channels 8g+4h .. 8g+4h+3 (h = lane >> 5) of its row, so the four MFMAs of a group
+//   consume k = (8g+e, 8g+4+e), e = 0..3: the chain order inside a 32-channel block is 0,4,1,5,2,6,3,7, 8,12,9,13, ...
+//   (oracle/unet_exact.c:conv_block walks the same order).
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int KC, int KS>
-__global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_mfma_kernel(ConvArgs a, int M, int Ho, int Wo, int nMt, int nNt)
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int BM, int BN, int WM, int WN, int KS, bool RELU>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_mfma_kernel(ConvArgs a, int M, int Ho, int Wo, int nMt, int nNt)
 {
     // KS (1, 2 or 3) is a template parameter so that the 3x3 and the pointwise instantiations are distinct kernels
-    // (distinct names in rocprofv3 traces: the 3x3 <128,128,2,2,32,3> instantiation is the dominant kernel).
+    // (distinct names in rocprofv3 traces: the 3x3 <128,128,2,2,3,*> instantiations are the dominant kernel).
     // KS == 2 is the sub-pixel form of a 3x3 convolution over a 2x nearest-upsampled input: output pixel
     // (2i + py, 2j + px) only sees the 2x2 stored pixels (i + py - 1 + {0,1}, j + px - 1 + {0,1}), with the 3x3 taps that
-    // fall on the same stored pixel pre-summed per parity class (weights [class][tap][Cin][Cout], class = blockIdx.y,
+    // fall on the same stored pixel pre-summed per parity class (weights [class][tap][Cout][Cin], class = blockIdx.y,
     // M enumerates the stored pixels).  4/9 of the multiply-adds of the as-written form.
-    static_assert(WM * WN == 4, "4 waves");
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
+    constexpr int NT = 64 * WM * WN;                 // threads
+    constexpr int RP = NT / 8;                       // rows per DMA pass: NT lanes x 16 B = RP rows of 128 B
+    constexpr int KC = 32;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int LDA = BM + 1;
-    constexpr int TPP = KC / 4;          // threads per pixel row of the A chunk (float4 each)
-    constexpr int PPP = 256 / TPP;       // pixels per staging pass
-    constexpr int NPA = BM / PPP;        // A passes
-    constexpr int BV = BN / 4;           // float4 per B row
-    constexpr int RPP = 256 / BV;        // B rows per pass
-    constexpr int NPB = KC / RPP;        // B passes
-    static_assert(NPA >= 1 && NPB >= 1, "tile config");
-
-    // one LDS array: [2][KC*BN] weight chunks (16-byte aligned), then [2][KC*LDA] pixel chunks; the epilogue
-    // reuses it as a [128][BN] output staging tile
-    constexpr int EPR = 128;
-    constexpr int SM_MAIN = 2 * KC * BN + 2 * KC * LDA;
-    constexpr int SM = SM_MAIN > EPR * BN ? SM_MAIN : EPR * BN;
-    __shared__ __attribute__((aligned(16))) float smem[SM];
-    float(*Bs)[KC * BN] = reinterpret_cast<float(*)[KC * BN]>(smem);
-    float(*As)[KC * LDA] = reinterpret_cast<float(*)[KC * LDA]>(smem + 2 * KC * BN);
+    constexpr int NPA = BM / RP, NPB = BN / RP;      // DMA passes
+    constexpr int STAGE = (BM + BN) * KC;            // floats per stage: A rows, then B rows
+    constexpr int EPR = 128 * BN <= STAGE ? 128 : 64;   // rows of the epilogue staging tile (it reuses stage 0)
+    static_assert(EPR * BN <= STAGE, "epilogue tile fits one stage");
+    static_assert(NPA >= 1 && NPA <= 8 && NPA * RP == BM, "A passes");
+    static_assert(NPB >= 1 && NPB <= 4 && NPB * RP == BN, "B passes");
+    static_assert(TM >= 1 && TN >= 1, "wave tile");
+    // Two separate LDS objects, one per stage: hipcc can then tell that the DMA in flight into one stage does not alias
+    // the ds_reads of the other (with a single array it waits vmcnt(0) before the first ds_read of every chunk, which
+    // serialises the DMA with the MFMAs).
+    __shared__ __attribute__((aligned(16))) float stage0[STAGE];
+    __shared__ __attribute__((aligned(16))) float stage1[STAGE];
 
     // XCD-aware tile mapping: blocks b and b+8 share an XCD (round-robin dispatch); give the
     // nNt column tiles of one pixel tile to the same XCD so its L2 serves the re-read A pixels.
     const int b = blockIdx.x;
-    // Co-resident blocks of one CU (2 per CU here) are dispatched together and would run in lockstep: both in their
-    // staging / barrier phase at the same time, both competing for the MFMA pipe at the same time.  Delaying every
-    // second generation of 256 blocks by about half a K-chunk period keeps the pairs out of phase for the whole launch.
-    if ((b >> 8) & 1)
-        for (int i = 0; i < (a.stagger & 255); i++) __builtin_amdgcn_s_sleep(8);
     const int xcd = b & 7, j = b >> 3;
     const int nt = j % nNt;
     const int mt = (j / nNt) * 8 + xcd;
@@ -71,133 +73,91 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_mfma_kernel(Conv
     const int m0 = mt * BM, n0 = nt * BN;
 
     const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    const int H = a.h << a.up, W = a.w << a.up;
     const int spy = KS == 2 ? (int)(blockIdx.y >> 1) : 0, spx = KS == 2 ? (int)(blockIdx.y & 1) : 0;
     constexpr int taps = KS * KS;
     const int cchunks = a.Cin / KC;
     const int nchunks = taps * cchunks;
 
-    // per-thread pixel bookkeeping for A staging: pointer to the centre tap's pixel, a 9-bit mask of the taps that fall
-    // inside the image, and (for nearest-upsampled inputs) the parities of y and x
-    const int c4 = (t % TPP) * 4;
-    const float *pc[NPA];
-    unsigned pm[NPA];
+    // DMA role of this lane: row (t >> 3) of every RP-row pass, slot t & 7, i.e. channel group (t & 7) ^ (row & 7).
+    // The DMA is a raw buffer load (buffer_load_dwordx4 ... lds): address = buffer base + per-lane voffset + scalar
+    // soffset.  The A buffer starts (w + 1) stored pixels before the tile's first pixel, the per-lane voffset is the
+    // pixel's distance from that first pixel (fixed for the whole kernel), and the tap / channel-block displacement
+    // ((dy + 1) w + dx + 1) Cin + 32 cb is the scalar soffset: no per-chunk 64-bit address math.  Out-of-image taps (and
+    // rows past M) use a voffset beyond num_records: the buffer range check makes the load return zeros.
+    const int srow = t >> 3;
+    const int c4 = ((t & 7) ^ (srow & 7)) * 4;
+    constexpr unsigned OOB = 0x80000000u;
+    auto stored_pixel = [&](int m) {     // linear index of the stored pixel that output pixel m is centred on
+        const int n = m / (Ho * Wo);
+        const int r = m - n * (Ho * Wo);
+        const int yo = r / Wo;
+        return (n * a.h + yo * a.stride) * a.w + (r - yo * Wo) * a.stride;
+    };
+    const int p0 = __builtin_amdgcn_readfirstlane(stored_pixel(m0));
+    unsigned pv[NPA];       // voffset (bytes) of the staged pixel's channel group
+    unsigned pm[NPA];       // mask of the taps that fall inside the image
 #pragma unroll
     for (int i = 0; i < NPA; i++) {
-        const int m = m0 + i * PPP + t / TPP;
+        const int m = m0 + i * RP + srow;
         const bool ok = m < M;
-        const int mm = ok ? m : 0;
+        const int mm = ok ? m : m0;
         const int n = mm / (Ho * Wo);
         const int r = mm - n * (Ho * Wo);
         const int yo = r / Wo;
         const int y = yo * a.stride, x = (r - yo * Wo) * a.stride;
-        pc[i] = a.in + ((size_t)(n * a.h + (y >> a.up)) * a.w + (x >> a.up)) * a.Cin + c4;
+        pv[i] = (unsigned)(((n * a.h + y) * a.w + x - p0) * a.Cin + c4) * 4u;
         unsigned msk = 0;
         if (ok) {
             if (KS == 3) {
 #pragma unroll
                 for (int tp = 0; tp < 9; tp++) {
                     const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
-                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) msk |= 1u << tp;
+                    if (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) msk |= 1u << tp;
                 }
             } else if (KS == 2) {
 #pragma unroll
                 for (int tp = 0; tp < 4; tp++) {
                     const int yy = y + spy - 1 + (tp >> 1), xx = x + spx - 1 + (tp & 1);
-                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) msk |= 1u << tp;
+                    if (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) msk |= 1u << tp;
                 }
             } else msk = 1u;
         }
-        pm[i] = msk | ((unsigned)(y & 1) << 9) | ((unsigned)(x & 1) << 10);
+        pm[i] = msk;
     }
-    const int brow = t / BV, bcol = (t % BV) * 4;
+    const __amdgpu_buffer_rsrc_t rsA =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + ((long)p0 - a.w - 1) * a.Cin), 0, 0x7fffffff, 0x00020000);
+    // weights [tap][Cout][Cin] (KS == 2: [class][tap][Cout][Cin]): row n0 + pass * RP + srow, this lane's channel group
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.W + (KS == 2 ? (size_t)blockIdx.y * 4 * a.Cin * a.Cout : (size_t)0) + (size_t)n0 * a.Cin), 0, 0x7fffffff, 0x00020000);
+    const unsigned wv = (unsigned)(srow * a.Cin + c4) * 4u;
+    const int wtap = a.Cout * a.Cin * 4;             // bytes per tap
+    const int wpass = RP * a.Cin * 4;                // bytes per DMA pass of weight rows
+    const int ldsw = wave * 8 * KC;                  // this wave's 8 rows (1 KiB) inside an RP-row pass
 
-    // Loads are unconditional (out-of-image taps read a valid dummy address and are zeroed when the
-    // registers are written to LDS), so the next chunk's global loads stay in flight across the MFMA loop.
-    // Two register sets (P, Q) hold the chunks c+1 and c+2 while chunk c is multiplied: a chunk's global loads
-    // have two MFMA phases (~8k cycles) to land before they are written to LDS.
-    // Loader state machine (chunks are loaded strictly in order): per staged pixel a base pointer for the current
-    // tap -- the input pixel, or a zero row for out-of-image taps, so the loads are unconditional and need no
-    // select afterwards -- recomputed only when the tap changes; the weight pointer just advances by KC rows
-    // (W is [tap][Cin][Cout], i.e. chunk after chunk is contiguous).
-    float4 pa0, pa1, pa2, pa3, pa4, pa5, pa6, pa7, pb0, pb1, pb2, pb3;
-    float4 qa0, qa1, qa2, qa3, qa4, qa5, qa6, qa7, qb0, qb1, qb2, qb3;
-    static_assert(NPA == 4 || NPA == 8 || NPA == 2, "A passes");
-    static_assert(NPB == 4 || NPB == 2 || NPB == 1, "B passes");
-    const float *ab0 = a.zeros, *ab1 = a.zeros, *ab2 = a.zeros, *ab3 = a.zeros, *ab4 = a.zeros, *ab5 = a.zeros, *ab6 = a.zeros,
-                *ab7 = a.zeros;
-    const float *wbase = a.W + (KS == 2 ? (size_t)blockIdx.y * 4 * a.Cin * a.Cout : (size_t)0) + n0 + bcol + (size_t)brow * a.Cout;
-    // chunk order: 32-channel block major, then tap, then (KC = 16 only) the two halves of the block
-    constexpr int HPB = 32 / KC;            // chunks per (block, tap)
-    int ld_cb = 0, ld_tap = 0, ld_half = 0, ld_cc = 0;
-
-#define TMAT_BASE(i, AB)                                                                                    \
-    if (i < NPA) {                                                                                          \
-        /* tap offset in stored pixels: (dy, dx) itself, or ((parity + d) >> 1) for a nearest-upsampled input */ \
-        const int ddy = a.up ? (((int)((pm[i] >> 9) & 1u) + dy) >> 1) : dy;                                 \
-        const int ddx = a.up ? (((int)((pm[i] >> 10) & 1u) + dx) >> 1) : dx;                                \
-        const bool ok = (pm[i] >> ld_tap) & 1u;                                                             \
-        AB = ok ? pc[i] + (ddy * a.w + ddx) * a.Cin : a.zeros + c4;                                         \
+    int ld_cb = 0, ld_tap = 0;
+#define TMAT_DMA_A(i)                                                                                        \
+    if (i < NPA) {                                                                                           \
+        const unsigned vo = (pm[i] & tbit) ? pv[i] : OOB;                                                    \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t *)(st + i * RP * KC + ldsw), 16, vo, soA, 0, 0); \
     }
-#define TMAT_LOAD_CHUNK(S)                                                             \
+#define TMAT_DMA_B(i)                                                                                        \
+    if (i < NPB)                                                                                             \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t *)(st + (BM + i * RP) * KC + ldsw), 16, wv, soB + i * wpass, 0, 0);
+#define TMAT_ISSUE_CHUNK(stage_)                                                       \
     {                                                                                  \
-        if (ld_half == 0 && ld_cc < nchunks) {                                         \
-            const int dy = KS == 3 ? ld_tap / 3 - 1 : KS == 2 ? spy - 1 + (ld_tap >> 1) : 0; \
-            const int dx = KS == 3 ? ld_tap % 3 - 1 : KS == 2 ? spx - 1 + (ld_tap & 1) : 0;  \
-            TMAT_BASE(0, ab0) TMAT_BASE(1, ab1) TMAT_BASE(2, ab2) TMAT_BASE(3, ab3)    \
-            TMAT_BASE(4, ab4) TMAT_BASE(5, ab5) TMAT_BASE(6, ab6) TMAT_BASE(7, ab7)    \
-        }                                                                              \
-        const int ld_c0 = ld_cb * 32 + ld_half * KC;                                   \
-        const float *wp = wbase + ((size_t)ld_tap * a.Cin + ld_c0) * a.Cout;           \
-        if (0 < NPA) S##a0 = *reinterpret_cast<const float4 *>(ab0 + ld_c0);           \
-        if (1 < NPA) S##a1 = *reinterpret_cast<const float4 *>(ab1 + ld_c0);           \
-        if (2 < NPA) S##a2 = *reinterpret_cast<const float4 *>(ab2 + ld_c0);           \
-        if (3 < NPA) S##a3 = *reinterpret_cast<const float4 *>(ab3 + ld_c0);           \
-        if (4 < NPA) S##a4 = *reinterpret_cast<const float4 *>(ab4 + ld_c0);           \
-        if (5 < NPA) S##a5 = *reinterpret_cast<const float4 *>(ab5 + ld_c0);           \
-        if (6 < NPA) S##a6 = *reinterpret_cast<const float4 *>(ab6 + ld_c0);           \
-        if (7 < NPA) S##a7 = *reinterpret_cast<const float4 *>(ab7 + ld_c0);           \
-        if (0 < NPB) S##b0 = *reinterpret_cast<const float4 *>(wp);                    \
-        if (1 < NPB) S##b1 = *reinterpret_cast<const float4 *>(wp + (size_t)(1 * RPP) * a.Cout); \
-        if (2 < NPB) S##b2 = *reinterpret_cast<const float4 *>(wp + (size_t)(2 * RPP) * a.Cout); \
-        if (3 < NPB) S##b3 = *reinterpret_cast<const float4 *>(wp + (size_t)(3 * RPP) * a.Cout); \
-        /* the loads are issued unconditionally (a guard would force the compiler to drain the prefetch at every   \
-           LDS store); past the last chunk the state simply stops advancing and the last chunk is re-read, unused */ \
-        ld_cc++;                                                                       \
-        if (ld_cc < nchunks) {                                                         \
-            if (++ld_half == HPB) { ld_half = 0; if (++ld_tap == taps) { ld_tap = 0; ld_cb++; } } \
-        }                                                                              \
-    }
-#define TMAT_STORE_A(i, R)                                                             \
-    if (i < NPA) {                                                                     \
-        float *d = &As[bb][c4 * LDA + i * PPP + t / TPP];                              \
-        if (a.relu_in) { d[0] = fmaxf(R.x, 0.f); d[LDA] = fmaxf(R.y, 0.f); d[2 * LDA] = fmaxf(R.z, 0.f); d[3 * LDA] = fmaxf(R.w, 0.f); } \
-        else { d[0] = R.x; d[LDA] = R.y; d[2 * LDA] = R.z; d[3 * LDA] = R.w; }         \
-    }
-#define TMAT_STORE_B(i, R) \
-    if (i < NPB) *reinterpret_cast<float4 *>(&Bs[bb][(i * RPP + brow) * BN + bcol]) = R;
-#define TMAT_STORE_CHUNK(buf_, S)                                                      \
-    {                                                                                  \
-        const int bb = (buf_);                                                         \
-        TMAT_STORE_A(0, S##a0) TMAT_STORE_A(1, S##a1) TMAT_STORE_A(2, S##a2) TMAT_STORE_A(3, S##a3) \
-        TMAT_STORE_A(4, S##a4) TMAT_STORE_A(5, S##a5) TMAT_STORE_A(6, S##a6) TMAT_STORE_A(7, S##a7) \
-        TMAT_STORE_B(0, S##b0) TMAT_STORE_B(1, S##b1) TMAT_STORE_B(2, S##b2) TMAT_STORE_B(3, S##b3) \
-    }
-#define TMAT_MFMA_CHUNK(buf_)                                                          \
-    {                                                                                  \
-        const float *Ab = &As[buf_][aoff];                                             \
-        const float *Bb = &Bs[buf_][boff];                                             \
-        _Pragma("unroll") for (int kk = 0; kk < KC / 2; kk++) {                        \
-            float av[TM], bv[TN];                                                      \
-            _Pragma("unroll") for (int i = 0; i < TM; i++) av[i] = Ab[kk * 2 * LDA + i * 32];   \
-            _Pragma("unroll") for (int jn = 0; jn < TN; jn++) bv[jn] = Bb[kk * 2 * BN + jn * 32]; \
-            _Pragma("unroll") for (int i = 0; i < TM; i++)                             \
-                _Pragma("unroll") for (int jn = 0; jn < TN; jn++)                      \
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[jn], acc[i][jn], 0, 0, 0); \
-        }                                                                              \
+        float *st = (stage_);                                                          \
+        const int dy = KS == 3 ? ld_tap / 3 - 1 : KS == 2 ? spy - 1 + (ld_tap >> 1) : 0; \
+        const int dx = KS == 3 ? ld_tap % 3 - 1 : KS == 2 ? spx - 1 + (ld_tap & 1) : 0;  \
+        const int soA = (((dy + 1) * a.w + dx + 1) * a.Cin + ld_cb * KC) * 4;          \
+        const int soB = ld_tap * wtap + ld_cb * KC * 4;                                \
+        const unsigned tbit = 1u << ld_tap;                                            \
+        TMAT_DMA_A(0) TMAT_DMA_A(1) TMAT_DMA_A(2) TMAT_DMA_A(3)                        \
+        TMAT_DMA_A(4) TMAT_DMA_A(5) TMAT_DMA_A(6) TMAT_DMA_A(7)                        \
+        TMAT_DMA_B(0) TMAT_DMA_B(1) TMAT_DMA_B(2) TMAT_DMA_B(3)                        \
+        if (++ld_tap == taps) { ld_tap = 0; ld_cb++; }                                 \
     }
 
     f32x16 acc[TM][TN];
@@ -208,35 +168,81 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_mfma_kernel(Conv
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][jn][r] = 0.f;
 
-    const int aoff = (lane >> 5) * LDA + wm * (BM / WM) + (lane & 31);
-    const int boff = (lane >> 5) * BN + wn * (BN / WN) + (lane & 31);
+    // fragment addressing: row = tile base + (lane & 31) (tile bases are multiples of 8, so the swizzle key is lane & 7),
+    // slot of channel group 2g + (lane >> 5) is (2g + (lane >> 5)) ^ (lane & 7)
+    const int arow = (wm * (BM / WM) + (lane & 31)) * KC;
+    const int brow = (BM + wn * (BN / WN) + (lane & 31)) * KC;
+    const int hi = lane >> 5, key = lane & 7;
 
-    TMAT_LOAD_CHUNK(p)
-    TMAT_STORE_CHUNK(0, p)
-    TMAT_LOAD_CHUNK(q)
-    __syncthreads();
-
-    // chunk c lives in LDS buffer c & 1; register set p carries even chunks, q odd ones (nchunks is even: host check)
-    for (int c = 0; c < nchunks; c += 2) {
-        TMAT_LOAD_CHUNK(p)
-        __builtin_amdgcn_sched_barrier(0);      // keep the staging math of prefetched chunks out of the MFMA loop
-        TMAT_MFMA_CHUNK(0)
-        __builtin_amdgcn_sched_barrier(0);
-        TMAT_STORE_CHUNK(1, q)                  // chunk c + 1
-        __syncthreads();
-        TMAT_LOAD_CHUNK(q)
-        __builtin_amdgcn_sched_barrier(0);
-        TMAT_MFMA_CHUNK(1)
-        __builtin_amdgcn_sched_barrier(0);
-        TMAT_STORE_CHUNK(0, p)                  // chunk c + 2
-        __syncthreads();
+    // ReLU on a fragment register: as a signed integer a negative float (and -0.0) is negative, so one v_max_i32 with 0
+    // gives relu(x) = x > 0 ? x : +0.0 exactly (no NaNs here), without fmaxf's canonicalisation.
+#define TMAT_RELU(v) __builtin_bit_cast(float, max(__builtin_bit_cast(int, (v)), 0))
+    // All 16 fragment reads of a chunk are issued up front (64 VGPRs), so only the first group of MFMAs waits for LDS.
+#define TMAT_MFMA_CHUNK(stage_)                                                        \
+    {                                                                                  \
+        const float *st = (stage_);                                                    \
+        float4 av[4][TM], bv[4][TN];                                                   \
+        _Pragma("unroll") for (int g = 0; g < 4; g++) {                                \
+            const int slot = ((2 * g + hi) ^ key) * 4;                                 \
+            _Pragma("unroll") for (int i = 0; i < TM; i++) av[g][i] = *reinterpret_cast<const float4 *>(st + arow + i * 32 * KC + slot); \
+            _Pragma("unroll") for (int jn = 0; jn < TN; jn++) bv[g][jn] = *reinterpret_cast<const float4 *>(st + brow + jn * 32 * KC + slot); \
+        }                                                                              \
+        __builtin_amdgcn_sched_barrier(0);      /* keep the reads ahead of the MFMAs (hipcc sinks them otherwise) */ \
+        _Pragma("unroll") for (int g = 0; g < 4; g++) {                                \
+            if (RELU) {                                                                \
+                _Pragma("unroll") for (int i = 0; i < TM; i++) {                       \
+                    av[g][i].x = TMAT_RELU(av[g][i].x); av[g][i].y = TMAT_RELU(av[g][i].y); \
+                    av[g][i].z = TMAT_RELU(av[g][i].z); av[g][i].w = TMAT_RELU(av[g][i].w); \
+                }                                                                      \
+            }                                                                          \
+            _Pragma("unroll") for (int i = 0; i < TM; i++)                             \
+                _Pragma("unroll") for (int jn = 0; jn < TN; jn++) {                    \
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][i].x, bv[g][jn].x, acc[i][jn], 0, 0, 0); \
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][i].y, bv[g][jn].y, acc[i][jn], 0, 0, 0); \
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][i].z, bv[g][jn].z, acc[i][jn], 0, 0, 0); \
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][i].w, bv[g][jn].w, acc[i][jn], 0, 0, 0); \
+                }                                                                      \
+        }                                                                              \
+        __builtin_amdgcn_sched_barrier(0);      /* ... and the MFMAs ahead of the barrier that retires the DMA */ \
     }
-#undef TMAT_BASE
-#undef TMAT_LOAD_CHUNK
-#undef TMAT_STORE_A
-#undef TMAT_STORE_B
-#undef TMAT_STORE_CHUNK
+
+    TMAT_ISSUE_CHUNK(stage0)
+    __syncthreads();                // retires the DMA (hipcc emits vmcnt(0) in front of the barrier)
+
+    // even chunks live in stage0, odd ones in stage1 (nchunks is even: host check)
+    // (TMAT_ABL_*: timing ablations for tools/gpu_variants.sh only -- they produce wrong results and are never defined
+    // in the shipped build.)
+#ifdef TMAT_ABL_NODMA
+#define TMAT_LOOP_ISSUE(st)
+#else
+#define TMAT_LOOP_ISSUE(st) TMAT_ISSUE_CHUNK(st)
+#endif
+#ifdef TMAT_ABL_NOMFMA
+#define TMAT_LOOP_MFMA(st)
+#else
+#define TMAT_LOOP_MFMA(st) TMAT_MFMA_CHUNK(st)
+#endif
+#ifdef TMAT_ABL_NOBAR
+#define TMAT_LOOP_SYNC()
+#else
+#define TMAT_LOOP_SYNC() __syncthreads();
+#endif
+    for (int c = 0; c < nchunks; c += 2) {
+        TMAT_LOOP_ISSUE(stage1)                         // chunk c + 1
+        TMAT_LOOP_MFMA(stage0)
+        TMAT_LOOP_SYNC()            // chunk c is consumed by every wave; chunk c + 1 has landed
+        if (c + 2 < nchunks) TMAT_LOOP_ISSUE(stage0)    // chunk c + 2
+        TMAT_LOOP_MFMA(stage1)
+        TMAT_LOOP_SYNC()
+    }
+#undef TMAT_LOOP_ISSUE
+#undef TMAT_LOOP_MFMA
+#undef TMAT_LOOP_SYNC
 #undef TMAT_MFMA_CHUNK
+#undef TMAT_RELU
+#undef TMAT_DMA_A
+#undef TMAT_DMA_B
+#undef TMAT_ISSUE_CHUNK
 
     // epilogue: accumulators -> LDS tile [128][BN] (C/D layout: col = lane & 31 is the output channel,
     // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) the pixel) -> BN fold / bias, residual, ReLU on float4 rows ->
@@ -244,8 +250,8 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_mfma_kernel(Conv
     {
         constexpr int NPASS = BM / EPR;
         constexpr int V4 = BN / 4;
-        constexpr int RPI = 256 / V4;            // rows per store iteration
-        float *Cs = smem;
+        constexpr int RPI = NT / V4;             // rows per store iteration
+        float *Cs = stage0;
         const int cv = (t % V4) * 4, r0 = t / V4;
         const int co = n0 + cv;
         float4 sc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -300,39 +306,47 @@ __global__ __launch_bounds__(256, (BN == 64 ? 3 : 2)) void conv_mfma_kernel(Conv
     }
 }
 
-template <int BM, int BN, int WM, int WN, int KC>
-static void launch_conv_cfg(const ConvArgs &a, int M, int Ho, int Wo, hipStream_t s)
+template <int BM, int BN, int WM, int WN, int KS>
+static void launch_conv_ks(const ConvArgs &a, int M, int Ho, int Wo, hipStream_t s)
 {
     int nMt = (M + BM - 1) / BM, nNt = a.Cout / BN;
-    int grid = ((nMt + 7) / 8) * 8 * nNt;
-    if (a.ksize == 3)
-        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KC, 3>), dim3(grid), dim3(256), 0, s, a, M, Ho, Wo, nMt, nNt);
-    else if (a.ksize == 2)
-        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KC, 2>), dim3(grid, 4), dim3(256), 0, s, a, M, Ho, Wo, nMt, nNt);
+    dim3 grid(((nMt + 7) / 8) * 8 * nNt, KS == 2 ? 4 : 1);
+    if (a.relu_in)
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, true>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt);
     else
-        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KC, 1>), dim3(grid), dim3(256), 0, s, a, M, Ho, Wo, nMt, nNt);
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, false>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt);
 }
+
+template <int BM, int BN, int WM, int WN>
+static void launch_conv_cfg(const ConvArgs &a, int M, int Ho, int Wo, hipStream_t s)
+{
+    if (a.ksize == 3) launch_conv_ks<BM, BN, WM, WN, 3>(a, M, Ho, Wo, s);
+    else if (a.ksize == 2) launch_conv_ks<BM, BN, WM, WN, 2>(a, M, Ho, Wo, s);
+    else launch_conv_ks<BM, BN, WM, WN, 1>(a, M, Ho, Wo, s);
+}
+
+#ifndef TMAT_WM
+#define TMAT_WM 2       // waves per block = TMAT_WM x TMAT_WN (4 x 2 measured equal within noise)
+#define TMAT_WN 2
+#endif
 
 bool launch_conv(const ConvArgs &a, hipStream_t s)
 {
-    const int H = a.h << a.up, W = a.w << a.up;
-    const int Ho = H / a.stride, Wo = W / a.stride;
+    const int Ho = a.h / a.stride, Wo = a.w / a.stride;
     const long long Mll = (long long)a.N * Ho * Wo;
-    if (!((a.ksize == 3 && a.stride == 1) || (a.ksize == 2 && a.stride == 1 && a.up == 0 && !a.resid) ||
-          (a.ksize == 1 && (a.stride == 1 || a.stride == 2))) || a.Cin % 32 ||
-        a.Cout % 64 || ((a.ksize * a.ksize * (a.Cin / (a.Cout % 128 == 0 ? 32 : 16))) & 1) || Mll <= 0 || Mll > 0x7fffffffLL / 2 || (a.resid && a.rs && ((Ho | Wo) & 1))) {
+    if (!((a.ksize == 3 && a.stride == 1) || (a.ksize == 2 && a.stride == 1 && !a.resid) ||
+          (a.ksize == 1 && (a.stride == 1 || a.stride == 2))) || a.up != 0 || a.Cin % 32 || a.Cout % 64 ||
+        ((a.ksize * a.ksize * (a.Cin / 32)) & 1) || Mll <= 0 ||
+        Mll > 0x7fffffffLL / 2 || (a.resid && a.rs && ((Ho | Wo) & 1))) {
         set_error("launch_conv: unsupported shape");
         return false;
     }
     const int M = (int)Mll;
-    static const int stagger = [] { const char *e = getenv("TMAT_STAGGER"); return e ? atoi(e) : 0; }();
     if (!a.zeros || a.Cin > 2048) { set_error("launch_conv: missing zero row or Cin > 2048"); return false; }
-    ConvArgs b = a;
-    b.stagger = stagger;
     if (a.Cout % 128 == 0)
-        launch_conv_cfg<128, 128, 2, 2, 32>(b, M, Ho, Wo, s);
+        launch_conv_cfg<128, 128, TMAT_WM, TMAT_WN>(a, M, Ho, Wo, s);
     else
-        launch_conv_cfg<256, 64, 4, 1, 16>(b, M, Ho, Wo, s);
+        launch_conv_cfg<128, 64, TMAT_WM, TMAT_WN>(a, M, Ho, Wo, s);
     return true;
 }
 
