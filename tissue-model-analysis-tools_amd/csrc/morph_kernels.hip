@@ -124,36 +124,66 @@ __global__ void region_stats_kernel(const int *__restrict__ L, int H, int W, int
     }
 }
 
-// ---- Zhang thinning: one parallel sub-iteration (reads `in`, writes `out`, raises changed[img]) ----
-__global__ void zhang_pass_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int H, int W, int pass,
-                                  int *__restrict__ changed, const int *__restrict__ done)
+// ---- Zhang thinning, ZH_IT full iterations (2 ZH_IT parallel sub-iterations) per launch ----
+// A sub-iteration moves information by one pixel, so a block that stages its ZH_TI x ZH_TI tile with a halo of
+// ZH_R = 2 ZH_IT pixels in LDS can run 2 ZH_IT sub-iterations locally and still hold the exact state of its inner
+// tile (the ring that would need pixels outside the staged tile shrinks inward by one pixel per sub-iteration and never
+// reaches the inner tile).  changed[launch][img] is raised when an inner-tile pixel is removed; a launch that removes
+// nothing leaves out == in, so every later launch of that image can return immediately (both buffers hold the result).
+constexpr int ZH_IT = 4, ZH_R = 2 * ZH_IT, ZH_TI = 48, ZH_T = ZH_TI + 2 * ZH_R;     // 64 x 64 staged pixels
+__global__ __launch_bounds__(256) void zhang_tile_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int H, int W,
+                                                         int tiles_x, const int *__restrict__ prev_changed, int *__restrict__ changed)
 {
-    if (done[blockIdx.y]) return;                 // this image converged earlier (its result sits in the pair's input buffer)
-    const size_t base = (size_t)blockIdx.y * H * W;
-    const uint8_t *s = in + base;
-    bool any = false;
-    IMG_LOOP(p, H * W) {
-        uint8_t v = s[p];
-        if (v) {
-            const int y = p / W, x = p - y * W;
-            auto at = [&](int yy, int xx) -> int { return (yy < 0 || yy >= H || xx < 0 || xx >= W) ? 0 : s[yy * W + xx]; };
-            const int code = at(y - 1, x - 1) + 2 * at(y - 1, x) + 4 * at(y - 1, x + 1) + 8 * at(y, x + 1) + 16 * at(y + 1, x + 1) +
-                             32 * at(y + 1, x) + 64 * at(y + 1, x - 1) + 128 * at(y, x - 1);
-            const int t = d_skel_lut[code];
-            if (t == 3 || (t == 1 && pass == 0) || (t == 2 && pass == 1)) { v = 0; any = true; }
-        }
-        out[base + p] = v;
+    const int img = blockIdx.y;
+    if (prev_changed && !prev_changed[img]) return;          // converged in an earlier launch
+    __shared__ uint8_t buf[2][ZH_T * ZH_T];
+    const size_t base = (size_t)img * H * W;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * ZH_TI - ZH_R, x0 = tx * ZH_TI - ZH_R;
+    const int t = threadIdx.x;
+    for (int idx = t; idx < ZH_T * ZH_T; idx += 256) {
+        const int y = y0 + idx / ZH_T, x = x0 + idx % ZH_T;
+        buf[0][idx] = (y >= 0 && y < H && x >= 0 && x < W) ? in[base + (size_t)y * W + x] : 0;
     }
-    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(&changed[blockIdx.y], 1);
+    __syncthreads();
+    bool any = false;
+    int cur = 0;
+#pragma unroll 1
+    for (int sub = 0; sub < 2 * ZH_IT; sub++) {
+        const uint8_t *s = buf[cur];
+        uint8_t *d = buf[cur ^ 1];
+        const int pass = sub & 1;
+        for (int idx = t; idx < ZH_T * ZH_T; idx += 256) {
+            const int ly = idx / ZH_T, lx = idx % ZH_T;
+            uint8_t v = s[idx];
+            if (v && ly > 0 && ly < ZH_T - 1 && lx > 0 && lx < ZH_T - 1) {
+                const uint8_t *q = s + idx;
+                const int code = q[-ZH_T - 1] + 2 * q[-ZH_T] + 4 * q[-ZH_T + 1] + 8 * q[1] + 16 * q[ZH_T + 1] + 32 * q[ZH_T] +
+                                 64 * q[ZH_T - 1] + 128 * q[-1];
+                const int tt = d_skel_lut[code];
+                if (tt == 3 || (tt == 1 && pass == 0) || (tt == 2 && pass == 1)) {
+                    v = 0;
+                    if (ly >= ZH_R && ly < ZH_R + ZH_TI && lx >= ZH_R && lx < ZH_R + ZH_TI) any = true;
+                }
+            }
+            d[idx] = v;
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+    for (int idx = t; idx < ZH_TI * ZH_TI; idx += 256) {
+        const int ly = idx / ZH_TI, lx = idx % ZH_TI;
+        const int y = y0 + ZH_R + ly, x = x0 + ZH_R + lx;
+        if (y < H && x < W) out[base + (size_t)y * W + x] = buf[cur][(ly + ZH_R) * ZH_T + lx + ZH_R];
+    }
+    if (__any(any) && (t & 63) == 0) atomicOr(&changed[img], 1);
 }
 
-// after each (first, second) pair: an image whose pair removed nothing is done
-__global__ void zhang_check_kernel(int *__restrict__ changed, int *__restrict__ done, int k)
+// converged <=> the last launch that could run removed nothing (its flag stayed 0)
+__global__ void zhang_done_kernel(const int *__restrict__ last_changed, int *__restrict__ done, int k)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= k) return;
-    if (!changed[i]) done[i] = 1;
-    changed[i] = 0;
+    if (i < k) done[i] = !last_changed[i];
 }
 
 // ---- skeleton components: fork flag and decision per skeleton root -> drop flag per mask root ----
@@ -269,7 +299,8 @@ size_t morph_workspace_bytes(int k, int H, int W)
 {
     const size_t npx = (size_t)k * H * W;
     // seg, med, skA, skB (u8) + ML, SL, g, area, n1, n2, n3, fork, drop (int) + st (2 ints) + flags
-    return npx * 4 + npx * sizeof(int) * 11 + 3 * (size_t)k * sizeof(int) + 4096;
+    const int launches = ((H > W ? H : W) / 2 + 8 + ZH_IT - 1) / ZH_IT + 1;      // thinning launches (filter_edt_dev)
+    return npx * 4 + npx * sizeof(int) * 11 + (3 + (size_t)launches) * k * sizeof(int) + 4096;
 }
 const int *morph_done_flags(void *workspace, int k, int H, int W)
 {
@@ -302,17 +333,23 @@ int filter_edt_dev(const double *pred, int k, int H, int W, int remove_isolated,
     hipLaunchKernelGGL(region_stats_kernel, grid, blk, 0, s, ML, H, W, area, n1, n2, n3);
     // Zhang thinning to convergence: (first, second) sub-iteration pairs until a whole pair removes nothing
     if (hipMemcpyAsync(skA, med, n, hipMemcpyDeviceToDevice, s) != hipSuccess) { set_error("morph: copy"); return -2; }
-    // No host round trip: every image carries a device-side `done` flag, converged images skip the remaining launches.
-    // A component of width w needs about w/2 pairs; max(H, W)/2 + 8 pairs always suffice (checked by the caller
-    // through flags[2k..3k) == 1, copied back with the results).
-    int *chg = flags, *done = flags + 2 * k;
-    if (hipMemsetAsync(flags, 0, 3 * k * sizeof(int), s) != hipSuccess) { set_error("morph: memset"); return -2; }
+    // No host round trip: changed[launch][image] flags live on the device; once a launch removes nothing for an image
+    // the remaining launches return at once.  A component of width w needs about w/2 iterations;
+    // max(H, W)/2 + 8 always suffice (checked by the caller through flags[2k..3k) == 1, copied back with the results).
+    int *done = flags + 2 * k;
     const int max_pairs = (H > W ? H : W) / 2 + 8;
-    for (int it = 0; it < max_pairs; it++) {
-        hipLaunchKernelGGL(zhang_pass_kernel, grid, blk, 0, s, skA, skB, H, W, 0, chg, done);
-        hipLaunchKernelGGL(zhang_pass_kernel, grid, blk, 0, s, skB, skA, H, W, 1, chg, done);
-        hipLaunchKernelGGL(zhang_check_kernel, dim3((k + 63) / 64), dim3(64), 0, s, chg, done, k);
+    const int launches = (max_pairs + ZH_IT - 1) / ZH_IT + 1;
+    int *chg = flags + 3 * k;            // [launches][k]
+    if (hipMemsetAsync(flags, 0, (size_t)(3 + launches) * k * sizeof(int), s) != hipSuccess) { set_error("morph: memset"); return -2; }
+    const int tiles_x = (W + ZH_TI - 1) / ZH_TI, tiles_y = (H + ZH_TI - 1) / ZH_TI;
+    const dim3 zgrid(tiles_x * tiles_y, k);
+    for (int it = 0; it < launches; it++) {
+        const uint8_t *src = (it & 1) ? skB : skA;
+        uint8_t *dst = (it & 1) ? skA : skB;
+        hipLaunchKernelGGL(zhang_tile_kernel, zgrid, blk, 0, s, src, dst, H, W, tiles_x, it ? chg + (size_t)(it - 1) * k : nullptr,
+                           chg + (size_t)it * k);
     }
+    hipLaunchKernelGGL(zhang_done_kernel, dim3((k + 63) / 64), dim3(64), 0, s, chg + (size_t)(launches - 1) * k, done, k);
     // skeleton components, fork test, decision, filtered mask
     hipLaunchKernelGGL(ccl_init_kernel, grid, blk, 0, s, skA, SL, npx);
     hipLaunchKernelGGL(ccl_merge_kernel, grid, blk, 0, s, skA, SL, H, W);

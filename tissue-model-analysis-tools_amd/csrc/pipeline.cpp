@@ -93,7 +93,11 @@ static int enqueue_segment(Ctx *c, const uint16_t *imgs_dev, int k, int slot)
 static int enqueue_front(Ctx *c, const uint16_t *imgs_dev, int k, int slot, const TileGeom &g)
 {
     PassBuf &b = c->pass;
-    hipStream_t s = c->stream2;
+    // Default: both halves on the main stream.  TMAT_STREAMS=2 puts this half on the second stream; measured +1.8 %
+    // images/s, but every kernel of the MFMA half then shares the CUs with a memory-bound one and its own duration
+    // (the roofline measurement) stretches by 20 %, so the overlap is opt-in.
+    static const bool one_stream = [] { const char *e = getenv("TMAT_STREAMS"); return !(e && atoi(e) == 2); }();
+    hipStream_t s = one_stream ? c->stream : c->stream2;
     launch_lanczos(imgs_dev, k, b.H, b.W, b.h, b.w, b.xi, b.xc, b.yi, b.yc, b.tmp, b.small, s);
     launch_rescale01(b.small, k, (size_t)b.h * b.w, b.mn, b.mx, b.x, s);
     float *mn = (float *)c->scratch, *mx = mn + k;

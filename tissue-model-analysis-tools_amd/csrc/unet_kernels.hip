@@ -37,7 +37,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 template <int BM, int BN, int WM, int WN, int KS, bool RELU>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_mfma_kernel(ConvArgs a, int M, int Ho, int Wo, int nMt, int nNt)
+__global__ __launch_bounds__(64 * WM * WN, ((BM + BN) * 256 > 65536 ? 2 : WM * WN == 8 ? 4 : 2)) void conv_mfma_kernel(ConvArgs a, int M, int Ho, int Wo, int nMt, int nNt)
 {
     // KS (1, 2 or 3) is a template parameter so that the 3x3 and the pointwise instantiations are distinct kernels
     // (distinct names in rocprofv3 traces: the 3x3 <128,128,2,2,3,*> instantiations are the dominant kernel).
@@ -177,17 +177,33 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_mfm
     // ReLU on a fragment register: as a signed integer a negative float (and -0.0) is negative, so one v_max_i32 with 0
     // gives relu(x) = x > 0 ? x : +0.0 exactly (no NaNs here), without fmaxf's canonicalisation.
 #define TMAT_RELU(v) __builtin_bit_cast(float, max(__builtin_bit_cast(int, (v)), 0))
-    // All 16 fragment reads of a chunk are issued up front (64 VGPRs), so only the first group of MFMAs waits for LDS.
-#define TMAT_MFMA_CHUNK(stage_)                                                        \
-    {                                                                                  \
-        const float *st = (stage_);                                                    \
-        float4 av[4][TM], bv[4][TN];                                                   \
+    // One step = one K chunk: all 16 fragment reads of the chunk are issued up front (64 VGPRs), then the DMA of the
+    // next chunk into the other stage, then the 64 MFMAs, then the barrier (hipcc puts the DMA's vmcnt(0) in front of it).
+    // sched_barrier(0) pins that order: left alone, hipcc sinks the reads next to their MFMAs and hoists the barrier.
+    // (TMAT_ABL_* / TMAT_VAR_*: timing experiments of tools/gpu_variants.sh; ablations produce wrong results and nothing
+    // of this is defined in the shipped build.)
+#if defined(TMAT_VAR_NOPIN)
+#define TMAT_PIN()
+#else
+#define TMAT_PIN() __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifdef TMAT_ABL_NODMA
+#define TMAT_LOOP_ISSUE(st)
+#else
+#define TMAT_LOOP_ISSUE(st) TMAT_ISSUE_CHUNK(st)
+#endif
+#ifdef TMAT_ABL_NOBAR
+#define TMAT_LOOP_SYNC()
+#else
+#define TMAT_LOOP_SYNC() __syncthreads();
+#endif
+#define TMAT_READ_FRAGS(stage_)                                                        \
         _Pragma("unroll") for (int g = 0; g < 4; g++) {                                \
             const int slot = ((2 * g + hi) ^ key) * 4;                                 \
-            _Pragma("unroll") for (int i = 0; i < TM; i++) av[g][i] = *reinterpret_cast<const float4 *>(st + arow + i * 32 * KC + slot); \
-            _Pragma("unroll") for (int jn = 0; jn < TN; jn++) bv[g][jn] = *reinterpret_cast<const float4 *>(st + brow + jn * 32 * KC + slot); \
-        }                                                                              \
-        __builtin_amdgcn_sched_barrier(0);      /* keep the reads ahead of the MFMAs (hipcc sinks them otherwise) */ \
+            _Pragma("unroll") for (int i = 0; i < TM; i++) av[g][i] = *reinterpret_cast<const float4 *>((stage_) + arow + i * 32 * KC + slot); \
+            _Pragma("unroll") for (int jn = 0; jn < TN; jn++) bv[g][jn] = *reinterpret_cast<const float4 *>((stage_) + brow + jn * 32 * KC + slot); \
+        }
+#define TMAT_MFMAS()                                                                   \
         _Pragma("unroll") for (int g = 0; g < 4; g++) {                                \
             if (RELU) {                                                                \
                 _Pragma("unroll") for (int i = 0; i < TM; i++) {                       \
@@ -202,43 +218,46 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8 ? 4 : 2)) void conv_mfm
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][i].z, bv[g][jn].z, acc[i][jn], 0, 0, 0); \
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][i].w, bv[g][jn].w, acc[i][jn], 0, 0, 0); \
                 }                                                                      \
-        }                                                                              \
-        __builtin_amdgcn_sched_barrier(0);      /* ... and the MFMAs ahead of the barrier that retires the DMA */ \
+        }
+#if defined(TMAT_VAR_ISSUEFIRST)
+#define TMAT_STEP(cur, nxt, more)                                                      \
+    {                                                                                  \
+        float4 av[4][TM], bv[4][TN];                                                   \
+        if (more) TMAT_LOOP_ISSUE(nxt)                                                 \
+        TMAT_READ_FRAGS(cur)                                                           \
+        TMAT_PIN()                                                                     \
+        TMAT_MFMAS()                                                                   \
+        TMAT_PIN()                                                                     \
+        TMAT_LOOP_SYNC()                                                               \
     }
+#else
+#define TMAT_STEP(cur, nxt, more)                                                      \
+    {                                                                                  \
+        float4 av[4][TM], bv[4][TN];                                                   \
+        TMAT_READ_FRAGS(cur)                                                           \
+        TMAT_PIN()                                                                     \
+        if (more) TMAT_LOOP_ISSUE(nxt)                                                 \
+        TMAT_PIN()                                                                     \
+        TMAT_MFMAS()                                                                   \
+        TMAT_PIN()                                                                     \
+        TMAT_LOOP_SYNC()                                                               \
+    }
+#endif
 
     TMAT_ISSUE_CHUNK(stage0)
     __syncthreads();                // retires the DMA (hipcc emits vmcnt(0) in front of the barrier)
 
     // even chunks live in stage0, odd ones in stage1 (nchunks is even: host check)
-    // (TMAT_ABL_*: timing ablations for tools/gpu_variants.sh only -- they produce wrong results and are never defined
-    // in the shipped build.)
-#ifdef TMAT_ABL_NODMA
-#define TMAT_LOOP_ISSUE(st)
-#else
-#define TMAT_LOOP_ISSUE(st) TMAT_ISSUE_CHUNK(st)
-#endif
-#ifdef TMAT_ABL_NOMFMA
-#define TMAT_LOOP_MFMA(st)
-#else
-#define TMAT_LOOP_MFMA(st) TMAT_MFMA_CHUNK(st)
-#endif
-#ifdef TMAT_ABL_NOBAR
-#define TMAT_LOOP_SYNC()
-#else
-#define TMAT_LOOP_SYNC() __syncthreads();
-#endif
     for (int c = 0; c < nchunks; c += 2) {
-        TMAT_LOOP_ISSUE(stage1)                         // chunk c + 1
-        TMAT_LOOP_MFMA(stage0)
-        TMAT_LOOP_SYNC()            // chunk c is consumed by every wave; chunk c + 1 has landed
-        if (c + 2 < nchunks) TMAT_LOOP_ISSUE(stage0)    // chunk c + 2
-        TMAT_LOOP_MFMA(stage1)
-        TMAT_LOOP_SYNC()
+        TMAT_STEP(stage0, stage1, true)                 // chunk c; DMA of chunk c + 1
+        TMAT_STEP(stage1, stage0, c + 2 < nchunks)      // chunk c + 1; DMA of chunk c + 2
     }
+#undef TMAT_STEP
+#undef TMAT_READ_FRAGS
+#undef TMAT_MFMAS
+#undef TMAT_PIN
 #undef TMAT_LOOP_ISSUE
-#undef TMAT_LOOP_MFMA
 #undef TMAT_LOOP_SYNC
-#undef TMAT_MFMA_CHUNK
 #undef TMAT_RELU
 #undef TMAT_DMA_A
 #undef TMAT_DMA_B
@@ -326,8 +345,13 @@ static void launch_conv_cfg(const ConvArgs &a, int M, int Ho, int Wo, hipStream_
 }
 
 #ifndef TMAT_WM
-#define TMAT_WM 2       // waves per block = TMAT_WM x TMAT_WN (4 x 2 measured equal within noise)
+#define TMAT_WM 4       // waves per block = TMAT_WM x TMAT_WN: 8 waves (32 x 64 outputs each) measured 2-4 % faster than 2 x 2
 #define TMAT_WN 2
+#endif
+#ifndef TMAT_64_BM
+#define TMAT_64_BM 128  // tile of the Cout = 64 layers
+#define TMAT_64_WM 4
+#define TMAT_64_WN 2
 #endif
 
 bool launch_conv(const ConvArgs &a, hipStream_t s)
@@ -346,7 +370,7 @@ bool launch_conv(const ConvArgs &a, hipStream_t s)
     if (a.Cout % 128 == 0)
         launch_conv_cfg<128, 128, TMAT_WM, TMAT_WN>(a, M, Ho, Wo, s);
     else
-        launch_conv_cfg<128, 64, TMAT_WM, TMAT_WN>(a, M, Ho, Wo, s);
+        launch_conv_cfg<TMAT_64_BM, 64, TMAT_64_WM, TMAT_64_WN>(a, M, Ho, Wo, s);
     return true;
 }
 
