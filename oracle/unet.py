@@ -188,8 +188,8 @@ def forward_exact(w, x, taps=None, subpixel=True):
         j += 1
     Nn, h, ww, C = S.shape
     out = np.empty((Nn, 2 * h, 2 * ww), np.float32)
-    L.orc_final(_p(S), Nn, h, ww, C, _p(_f32(w["final.w"].reshape(9, C))), ctypes.c_float(float(w["final.b"][0])),
-                _p(out))
+    wsub = _f32(subpixel_weights(w["final.w"].reshape(3, 3, C, 1)).reshape(4, 4, C))
+    L.orc_final(_p(S), Nn, h, ww, C, _p(wsub), ctypes.c_float(float(w["final.b"][0])), _p(out))
     return out
 
 

@@ -305,26 +305,31 @@ int orc_maxpool_add(const float *P2, int N, int H, int W, int C, const float *R,
     return 0;
 }
 
-/* final Conv2D(1, 3, activation="sigmoid", padding="same") on Up2(S) (models.py:158,166).
- * Wf layout [9][C]; out (N, 2h, 2w) */
-int orc_final(const float *S, int N, int h, int w, int C, const float *Wf, float bias, float *out)
+/* final Conv2D(1, 3, activation="sigmoid", padding="same") on Up2(S) (models.py:158,166), in the sub-pixel form of
+ * orc_conv_subpixel: output (2i + py, 2j + px) reads the stored pixels (i + py - 1 + a, j + px - 1 + b) with the 3x3 taps
+ * pre-summed per parity class.  Wsub layout [4 classes][4 slots][C] (unet.py:subpixel_weights of the (3,3,C,1) kernel).
+ * Chain order (shared with csrc/unet_kernels.hip:final_kernel): 4-channel group ascending, inside a group slot-major,
+ * then channel ascending; out-of-image stored pixels contribute fmaf(0, w, acc).  out (N, 2h, 2w) */
+int orc_final(const float *S, int N, int h, int w, int C, const float *Wsub, float bias, float *out)
 {
     int H = 2 * h, W = 2 * w;
+    static const float zeros[2048] = {0};
+    if (C > 2048 || C % 4) return -3;
 #pragma omp parallel for collapse(2) schedule(static)
     for (int n = 0; n < N; n++)
         for (int y = 0; y < H; y++)
             for (int x = 0; x < W; x++) {
-                float acc = 0.0f;
-                for (int t = 0; t < 9; t++) {
-                    int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
-                    const float *wr = Wf + (size_t)t * C;
-                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                        const float *ip = S + (((size_t)n * h + (iy >> 1)) * w + (ix >> 1)) * C;
-                        for (int c = 0; c < C; c++) acc = __builtin_fmaf(ip[c], wr[c], acc);
-                    } else {
-                        for (int c = 0; c < C; c++) acc = __builtin_fmaf(0.0f, wr[c], acc);
-                    }
+                const int i = y >> 1, py = y & 1, j = x >> 1, px = x & 1;
+                const float *Wc = Wsub + (size_t)(py * 2 + px) * 4 * C;
+                const float *ip[4];
+                for (int t = 0; t < 4; t++) {
+                    int iy = i + py - 1 + (t >> 1), ix = j + px - 1 + (t & 1);
+                    ip[t] = (iy >= 0 && iy < h && ix >= 0 && ix < w) ? S + (((size_t)n * h + iy) * w + ix) * C : zeros;
                 }
+                float acc = 0.0f;
+                for (int cg = 0; cg < C; cg += 4)
+                    for (int t = 0; t < 4; t++)
+                        for (int c = cg; c < cg + 4; c++) acc = __builtin_fmaf(ip[t][c], Wc[(size_t)t * C + c], acc);
                 out[((size_t)n * H + y) * W + x] = orc_sigmoid(acc + bias);
             }
     return 0;

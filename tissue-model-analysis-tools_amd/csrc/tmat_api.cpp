@@ -175,7 +175,16 @@ static bool build_model(Ctx *c, const std::map<std::string, Tensor> &m)
         cin = u.cout;
     }
     if (!need(m, "final.w", w) || !need(m, "final.b", b)) return false;
-    if (!upload(c, std::vector<float>(w.data, w.data + w.count), &c->final_w)) return false;
+    {   // final 3x3 conv over the upsampled tensor: sub-pixel form, laid out [C/4][class][slot][4] for unet_kernels.hip:final_kernel
+        const int C = cin;
+        if ((int)w.count != 9 * C || C % 4) { set_error("weights: final conv must be 3x3xCx1"); return false; }
+        const std::vector<float> sub = subpixel_weights(std::vector<float>(w.data, w.data + w.count), C, 1);   // [4][4][C]
+        std::vector<float> q((size_t)16 * C);
+        for (int cg = 0; cg < C / 4; cg++)
+            for (int ct = 0; ct < 16; ct++)
+                for (int e = 0; e < 4; e++) q[((size_t)cg * 16 + ct) * 4 + e] = sub[(size_t)ct * C + cg * 4 + e];
+        if (!upload(c, q, &c->final_w)) return false;
+    }
     c->final_b = b.data[0];
     c->f_last = cin;
     if (c->down.size() != c->up.size() - 1 || c->down.empty()) { set_error("weights: unexpected block structure"); return false; }
@@ -206,7 +215,7 @@ static void prof_end(Ctx *c, hipStream_t st)
 static bool conv(Ctx *c, ConvArgs a, hipStream_t st)
 {
     a.zeros = c->zero_row;
-    bool dom = a.ksize == 3 && a.Cout % 128 == 0;     // the conv_mfma_kernel<128,128,2,2,32,3> instantiation
+    bool dom = a.ksize == 3 && a.Cout % 128 == 0 && !a.relu_in;     // the conv_mfma_kernel<128,128,4,2,3,false> instantiation
     if (dom) {
         double H = (double)(a.h << a.up), W = (double)(a.w << a.up);
         prof_begin(c, 2.0 * a.N * H * W * 9.0 * a.Cin * a.Cout, st);

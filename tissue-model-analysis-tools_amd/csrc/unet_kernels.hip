@@ -376,49 +376,63 @@ bool launch_conv(const ConvArgs &a, hipStream_t s)
 
 // ---------------------------------------------------------------------------------------------
 // depthwise 3x3 (SeparableConv2D's depthwise half, models.py:131,135): chain over the 9 taps in
-// (ky, kx) order, zero padding, optional ReLU on load.  One thread = one pixel x 4 channels.
+// (ky, kx) order, zero padding, optional ReLU on load.
 // ---------------------------------------------------------------------------------------------
+constexpr int DW_ROWS = 8;      // output rows per thread (a 3-row window slides down the column strip)
 __global__ __launch_bounds__(256) void dwconv_kernel(const float *__restrict__ in, int H, int W, int C, int c4shift,
                                                      int relu_in, const float *__restrict__ Wd, float *__restrict__ out)
 {
-    // grid: (ceil(H * (W/4) * C4 / 256), N).  One thread = 4 consecutive pixels of a row x 4 channels: the 3 x 6
-    // input window is loaded once (18 float4 instead of 36).  32-bit index math; C4 = C/4 is a power of two.
+    // grid: (ceil((H/8) * (W/4) * C4 / 256), N).  One thread = a strip of 4 consecutive pixels x 8 rows x 4 channels.
+    // The 3 x 6 input window slides down the strip: every new output row costs 6 float4 loads for 4 float4 stores
+    // (1.9 loads per store over the strip instead of 4.5 for an isolated 3 x 6 window).  Lanes that are adjacent in the
+    // channel-group index read adjacent 16 B, so every load instruction moves whole 128-byte lines.
+    // 32-bit index math; C4 = C/4 is a power of two.
     const int n = blockIdx.y;
     const int e = blockIdx.x * 256 + threadIdx.x;
     const int C4 = 1 << c4shift;
     const int cq = e & (C4 - 1);
-    const int g = e >> c4shift;                 // pixel group index
+    const int g = e >> c4shift;                 // strip index
     const int WG = W >> 2;
-    if (g >= H * WG) return;
-    const int y = g / WG, x0 = (g - y * WG) * 4;
+    if (g >= (H / DW_ROWS) * WG) return;
+    const int ys = (g / WG) * DW_ROWS, x0 = (g % WG) * 4;
     const float *base = in + (size_t)n * H * W * C + cq * 4;
     const float lo = relu_in ? 0.f : -INFINITY;
-    float4 win[3][6];
-#pragma unroll
-    for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-            const int yy = y + r - 1, xx = x0 + c - 1;
-            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-            float4 v = *reinterpret_cast<const float4 *>(base + (ok ? (yy * W + xx) * C : 0));
-            v.x = ok ? fmaxf(v.x, lo) : 0.f; v.y = ok ? fmaxf(v.y, lo) : 0.f;
-            v.z = ok ? fmaxf(v.z, lo) : 0.f; v.w = ok ? fmaxf(v.w, lo) : 0.f;
-            win[r][c] = v;
-        }
     float4 wt[9];
 #pragma unroll
     for (int tp = 0; tp < 9; tp++) wt[tp] = *reinterpret_cast<const float4 *>(Wd + tp * C + cq * 4);
-    float *obase = out + ((size_t)n * H * W + (size_t)y * W + x0) * C + cq * 4;
+    bool xok[6];
 #pragma unroll
-    for (int px = 0; px < 4; px++) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < 6; c++) xok[c] = x0 + c - 1 >= 0 && x0 + c - 1 < W;
+    auto load_row = [&](int yy, float4 *row) {
+        const bool yok = yy >= 0 && yy < H;
 #pragma unroll
-        for (int tp = 0; tp < 9; tp++) {
-            const float4 v = win[tp / 3][px + tp % 3];
-            acc.x = fmaf(v.x, wt[tp].x, acc.x); acc.y = fmaf(v.y, wt[tp].y, acc.y);
-            acc.z = fmaf(v.z, wt[tp].z, acc.z); acc.w = fmaf(v.w, wt[tp].w, acc.w);
+        for (int c = 0; c < 6; c++) {
+            const bool ok = yok && xok[c];
+            float4 v = *reinterpret_cast<const float4 *>(base + (ok ? (yy * W + x0 + c - 1) * C : 0));
+            v.x = ok ? fmaxf(v.x, lo) : 0.f; v.y = ok ? fmaxf(v.y, lo) : 0.f;
+            v.z = ok ? fmaxf(v.z, lo) : 0.f; v.w = ok ? fmaxf(v.w, lo) : 0.f;
+            row[c] = v;
         }
-        *reinterpret_cast<float4 *>(obase + px * C) = acc;
+    };
+    float4 win[3][6];
+    load_row(ys - 1, win[0]);
+    load_row(ys, win[1]);
+    float *obase = out + ((size_t)n * H * W + (size_t)ys * W + x0) * C + cq * 4;
+#pragma unroll
+    for (int r = 0; r < DW_ROWS; r++) {
+        // rows (r, r + 1, r + 2) mod 3 of `win` hold input rows ys + r - 1, ys + r, ys + r + 1
+        load_row(ys + r + 1, win[(r + 2) % 3]);
+#pragma unroll
+        for (int px = 0; px < 4; px++) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int tp = 0; tp < 9; tp++) {
+                const float4 v = win[(r + tp / 3) % 3][px + tp % 3];
+                acc.x = fmaf(v.x, wt[tp].x, acc.x); acc.y = fmaf(v.y, wt[tp].y, acc.y);
+                acc.z = fmaf(v.z, wt[tp].z, acc.z); acc.w = fmaf(v.w, wt[tp].w, acc.w);
+            }
+            *reinterpret_cast<float4 *>(obase + ((size_t)r * W + px) * C) = acc;
+        }
     }
 }
 
@@ -427,7 +441,7 @@ static int ilog2(int v) { int s = 0; while ((1 << s) < v) s++; return s; }
 void launch_dwconv(const float *in, int N, int H, int W, int C, int relu_in, const float *Wd, float *out, hipStream_t s)
 {
     const int C4 = C / 4;
-    const int total = H * (W / 4) * C4;         // W % 4 == 0 for every level of the model (checked in tmat_create)
+    const int total = (H / DW_ROWS) * (W / 4) * C4;     // H % 8 == 0 and W % 4 == 0 for every level of the model (checked in tmat_create)
     hipLaunchKernelGGL(dwconv_kernel, dim3((total + 255) / 256, N), dim3(256), 0, s, in, H, W, C, ilog2(C4), relu_in, Wd, out);
 }
 
@@ -435,39 +449,56 @@ void launch_dwconv(const float *in, int N, int H, int W, int C, int relu_in, con
 // stem: Conv2D(C, 3, strides=2, "same") + BN + ReLU on the single-channel patch (models.py:119-121).
 // TF SAME with even H: taps read rows 2y .. 2y+2 (zero beyond the image).
 // ---------------------------------------------------------------------------------------------
+constexpr int STEM_PX = 8;      // output pixels (of one row) per thread
 __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ x, int H, int W, const float *__restrict__ Ws,
                                                    int Cout, int c4shift, const float *__restrict__ scale,
                                                    const float *__restrict__ shift, float *__restrict__ out)
 {
+    // One thread = 8 consecutive output pixels of a row x 4 channels: the 9 tap weights, scale and shift are loaded once
+    // per thread and the 3 x 17 input window once per strip (7.5 loads per 16-byte store instead of 18).
     const int Ho = H >> 1, Wo = W >> 1;
     const int n = blockIdx.y;
     const int e = blockIdx.x * 256 + threadIdx.x;
     const int cq = e & ((1 << c4shift) - 1);
-    const int p = e >> c4shift;
-    if (p >= Ho * Wo) return;
-    const int yo = p / Wo, xo = p - yo * Wo;
+    const int g = e >> c4shift;
+    const int WG = Wo / STEM_PX;
+    if (g >= Ho * WG) return;
+    const int yo = g / WG, xo0 = (g - yo * WG) * STEM_PX;
     const float *xin = x + (size_t)n * H * W;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 wt[9];
 #pragma unroll
-    for (int tp = 0; tp < 9; tp++) {
-        const int iy = 2 * yo + tp / 3, ix = 2 * xo + tp % 3;
-        const float v = (iy < H && ix < W) ? xin[iy * W + ix] : 0.f;
-        const float4 w = *reinterpret_cast<const float4 *>(Ws + tp * Cout + cq * 4);
-        acc.x = fmaf(v, w.x, acc.x); acc.y = fmaf(v, w.y, acc.y);
-        acc.z = fmaf(v, w.z, acc.z); acc.w = fmaf(v, w.w, acc.w);
-    }
+    for (int tp = 0; tp < 9; tp++) wt[tp] = *reinterpret_cast<const float4 *>(Ws + tp * Cout + cq * 4);
     const float4 sc = *reinterpret_cast<const float4 *>(scale + cq * 4);
     const float4 sh = *reinterpret_cast<const float4 *>(shift + cq * 4);
-    float4 o;
-    o.x = fmaxf(fmaf(acc.x, sc.x, sh.x), 0.f); o.y = fmaxf(fmaf(acc.y, sc.y, sh.y), 0.f);
-    o.z = fmaxf(fmaf(acc.z, sc.z, sh.z), 0.f); o.w = fmaxf(fmaf(acc.w, sc.w, sh.w), 0.f);
-    *reinterpret_cast<float4 *>(out + ((size_t)n * Ho * Wo + p) * Cout + cq * 4) = o;
+    float win[3][2 * STEM_PX + 1];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 2 * STEM_PX + 1; c++) {
+            const int iy = 2 * yo + r, ix = 2 * xo0 + c;
+            win[r][c] = (iy < H && ix < W) ? xin[iy * W + ix] : 0.f;
+        }
+    float *obase = out + ((size_t)n * Ho * Wo + (size_t)yo * Wo + xo0) * Cout + cq * 4;
+#pragma unroll
+    for (int px = 0; px < STEM_PX; px++) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int tp = 0; tp < 9; tp++) {
+            const float v = win[tp / 3][2 * px + tp % 3];
+            acc.x = fmaf(v, wt[tp].x, acc.x); acc.y = fmaf(v, wt[tp].y, acc.y);
+            acc.z = fmaf(v, wt[tp].z, acc.z); acc.w = fmaf(v, wt[tp].w, acc.w);
+        }
+        float4 o;
+        o.x = fmaxf(fmaf(acc.x, sc.x, sh.x), 0.f); o.y = fmaxf(fmaf(acc.y, sc.y, sh.y), 0.f);
+        o.z = fmaxf(fmaf(acc.z, sc.z, sh.z), 0.f); o.w = fmaxf(fmaf(acc.w, sc.w, sh.w), 0.f);
+        *reinterpret_cast<float4 *>(obase + (size_t)px * Cout) = o;
+    }
 }
 
 void launch_stem(const float *x, int N, int H, int W, const float *Ws, int Cout, const float *scale,
                  const float *shift, float *out, hipStream_t s)
 {
-    const int total = (H / 2) * (W / 2) * (Cout / 4);
+    const int total = (H / 2) * (W / 2 / STEM_PX) * (Cout / 4);     // (W / 2) % 8 == 0: patch size is a multiple of 64
     hipLaunchKernelGGL(stem_kernel, dim3((total + 255) / 256, N), dim3(256), 0, s, x, H, W, Ws, Cout, ilog2(Cout / 4), scale, shift, out);
 }
 
@@ -528,56 +559,79 @@ __device__ __forceinline__ float exp_det(float x)
     return ldexpf(y, (int)n);
 }
 
-// One block = 32 x 8 output pixels of one patch.  The (6 x 18) low-resolution pixels they touch are staged in LDS
-// (pixel stride padded to C + 4 floats so the 16-byte channel reads of neighbouring pixels do not collide), weights in LDS.
-__global__ __launch_bounds__(256) void final_kernel(const float *__restrict__ S, int h, int w, int C,
-                                                    const float *__restrict__ Wf, float bias, float *__restrict__ out)
+// final Conv2D(1, 3, sigmoid) over the 2x nearest-upsampled tensor, in sub-pixel form (see conv_mfma_kernel, KS == 2):
+// output (2i + py, 2j + px) = sum over the stored pixels (i + py - 1 + a, j + px - 1 + b) of pre-summed taps.
+// One thread = the 2 x 2 outputs above stored pixel (i, j): its 3 x 3 stored neighbourhood is read once from LDS per
+// 4-channel group and feeds the 16 (class, slot) products.  Chain order per output (shared with oracle orc_final):
+// 4-channel group ascending, inside a group slot-major (a, b), then channel ascending.  Weights Wq laid out
+// [C/4][4 classes][4 slots][4] are wave-uniform: hipcc reads them with scalar loads, so LDS only carries the pixels.
+// One block = 8 x 16 stored pixels (16 x 32 outputs); the 10 x 18 stored pixels they touch are staged in LDS with the
+// pixel stride padded to C + 4 floats (conflict-free 16-byte reads of neighbouring pixels).
+__global__ __launch_bounds__(128) void final_kernel(const float *__restrict__ S, int h, int w, int C,
+                                                    const float *__restrict__ Wq, float bias, float *__restrict__ out)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(16))) float tile[];    // [10][18][C + 4]
     const int CP = C + 4;
-    float *wsh = smem;                       // [9][C]
-    float *tile = smem + 9 * C;              // [6][18][CP]
-    const int H = 2 * h, W = 2 * w;
     const int n = blockIdx.z;
-    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 8;
-    const int ly0 = (y0 - 1) >> 1, lx0 = (x0 - 1) >> 1;     // floor division also for -1
-    for (int i = threadIdx.x; i < 9 * C; i += 256) wsh[i] = Wf[i];
+    const int j0 = blockIdx.x * 16, i0 = blockIdx.y * 8;
     const int C4 = C >> 2;
-    for (int i = threadIdx.x; i < 6 * 18 * C4; i += 256) {
-        const int cq = i % C4, p = i / C4;
-        const int ly = ly0 + p / 18, lx = lx0 + p % 18;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ly >= 0 && ly < h && lx >= 0 && lx < w) v = *reinterpret_cast<const float4 *>(S + (((size_t)n * h + ly) * w + lx) * C + cq * 4);
-        *reinterpret_cast<float4 *>(tile + p * CP + cq * 4) = v;
-    }
-    __syncthreads();
-    const int x = x0 + (threadIdx.x & 31), y = y0 + (threadIdx.x >> 5);
-    if (x >= W || y >= H) return;
-    float acc = 0.f;
-    for (int tp = 0; tp < 9; tp++) {
-        const int iy = y + tp / 3 - 1, ix = x + tp % 3 - 1;
-        const float *wr = wsh + tp * C;
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-            const float *ip = tile + (((iy >> 1) - ly0) * 18 + ((ix >> 1) - lx0)) * CP;
-            for (int c = 0; c < C; c += 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(ip + c);
-                const float4 ww = *reinterpret_cast<const float4 *>(wr + c);
-                acc = fmaf(v.x, ww.x, acc); acc = fmaf(v.y, ww.y, acc);
-                acc = fmaf(v.z, ww.z, acc); acc = fmaf(v.w, ww.w, acc);
-            }
-        } else {
-            for (int c = 0; c < C; c++) acc = fmaf(0.f, wr[c], acc);
+    // tile fill in batches of 8 loads per thread (all in flight together), then 8 LDS stores
+    const int total = 10 * 18 * C4;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 128 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = e0 + u * 128;
+            const int cq = e % C4, p = e / C4;
+            const int ly = i0 - 1 + p / 18, lx = j0 - 1 + p % 18;
+            const bool ok = e < total && ly >= 0 && ly < h && lx >= 0 && lx < w;
+            v[u] = *reinterpret_cast<const float4 *>(S + (ok ? (((size_t)n * h + ly) * w + lx) * C + cq * 4 : (size_t)0));
+            if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = e0 + u * 128;
+            if (e < total) *reinterpret_cast<float4 *>(tile + (e / C4) * CP + (e % C4) * 4) = v[u];
         }
     }
-    const float z = acc + bias;
-    out[((size_t)n * H + y) * W + x] = 1.0f / (1.0f + exp_det(-z));
+    __syncthreads();
+    const int qy = threadIdx.x >> 4, qx = threadIdx.x & 15;
+    const int i = i0 + qy, jj = j0 + qx;
+    if (i >= h || jj >= w) return;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};             // classes (py, px) = (0,0), (0,1), (1,0), (1,1)
+    const float *t0 = tile + (qy * 18 + qx) * CP;    // stored pixel (i - 1, j - 1)
+    for (int cg = 0; cg < C4; cg++) {
+        float4 v[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) v[r][c] = *reinterpret_cast<const float4 *>(t0 + (r * 18 + c) * CP + cg * 4);
+        const float *wq = Wq + cg * 64;
+#pragma unroll
+        for (int cls = 0; cls < 4; cls++)
+#pragma unroll
+            for (int tp = 0; tp < 4; tp++) {
+                const float4 x = v[(cls >> 1) + (tp >> 1)][(cls & 1) + (tp & 1)];
+                const float *ww = wq + (cls * 4 + tp) * 4;
+                acc[cls] = fmaf(x.x, ww[0], acc[cls]); acc[cls] = fmaf(x.y, ww[1], acc[cls]);
+                acc[cls] = fmaf(x.z, ww[2], acc[cls]); acc[cls] = fmaf(x.w, ww[3], acc[cls]);
+            }
+    }
+    const int W = 2 * w;
+    float *o = out + ((size_t)n * 2 * h + 2 * i) * W + 2 * jj;
+    float2 r0, r1;
+    r0.x = 1.0f / (1.0f + exp_det(-(acc[0] + bias))); r0.y = 1.0f / (1.0f + exp_det(-(acc[1] + bias)));
+    r1.x = 1.0f / (1.0f + exp_det(-(acc[2] + bias))); r1.y = 1.0f / (1.0f + exp_det(-(acc[3] + bias)));
+    *reinterpret_cast<float2 *>(o) = r0;
+    *reinterpret_cast<float2 *>(o + W) = r1;
 }
 
-void launch_final(const float *S, int N, int h, int w, int C, const float *Wf, float bias, float *out, hipStream_t s)
+// Wq: [C/4][4][4][4] (tmat_api.cpp:final_subpixel_weights)
+void launch_final(const float *S, int N, int h, int w, int C, const float *Wq, float bias, float *out, hipStream_t s)
 {
-    dim3 grid((2 * w + 31) / 32, (2 * h + 7) / 8, N);
-    const size_t lds = (size_t)(9 * C + 6 * 18 * (C + 4)) * sizeof(float);
-    hipLaunchKernelGGL(final_kernel, grid, dim3(256), lds, s, S, h, w, C, Wf, bias, out);
+    dim3 grid((w + 15) / 16, (h + 7) / 8, N);
+    const size_t lds = (size_t)(10 * 18 * (C + 4)) * sizeof(float);
+    hipLaunchKernelGGL(final_kernel, grid, dim3(128), lds, s, S, h, w, C, Wq, bias, out);
 }
 
 }  // namespace tmat

@@ -11,7 +11,7 @@ import sys
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parents[1]
-DOM = "conv_mfma_kernel<128, 128, 2, 2, 32, 3>"
+DOM = "conv_mfma_kernel<128, 128, 4, 2, 3, false>"
 
 
 def main(rnd):
