@@ -71,11 +71,28 @@ __device__ __forceinline__ void uf_union(int *L, int a, int b)
         a = old;
     }
 }
-__global__ void ccl_init_kernel(const uint8_t *__restrict__ m, int *__restrict__ L, int npx)
+// Initial label = the first pixel of the pixel's horizontal run inside its 64-pixel chunk (a wave covers 64 consecutive
+// flattened indices, so the run start comes from one ballot): runs are already merged, and every label is <= its index.
+__global__ void ccl_init_kernel(const uint8_t *__restrict__ m, int *__restrict__ L, int H, int W)
 {
-    const size_t base = (size_t)blockIdx.y * npx;
-    IMG_LOOP(p, npx) L[base + p] = m[base + p] ? p : -1;
+    const size_t base = (size_t)blockIdx.y * H * W;
+    IMG_LOOP(p, H * W) {
+        const bool set = m[base + p] != 0;
+        const unsigned long long on = __ballot(set);
+        const int lane = p & 63;                               // blockDim and the grid stride are multiples of 64
+        const int x = p % W;
+        const int first = lane - (lane < x ? lane : x);        // first lane of this chunk that lies in the same row
+        // zeros among the lanes [first, lane): the run starts just after the highest of them
+        const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+        const unsigned long long span = below & (first ? ~(~0ull >> (64 - first)) : ~0ull);
+        const unsigned long long zeros = ~on & span;
+        const int start = zeros ? 64 - __clzll(zeros) : first;
+        L[base + p] = set ? p - (lane - start) : -1;
+    }
 }
+// Unions that the run initialisation and the neighbours' own unions do not already imply:
+//   west, only across a chunk boundary;  north unless west and north-west are set (then W-NW-N already connects);
+//   without north: north-west unless west is set (W's north is NW), and north-east.
 __global__ void ccl_merge_kernel(const uint8_t *__restrict__ m, int *__restrict__ L, int H, int W)
 {
     const size_t base = (size_t)blockIdx.y * H * W;
@@ -84,11 +101,15 @@ __global__ void ccl_merge_kernel(const uint8_t *__restrict__ m, int *__restrict_
     IMG_LOOP(p, H * W) {
         if (!mm[p]) continue;
         const int y = p / W, x = p - y * W;
-        if (x > 0 && mm[p - 1]) uf_union(LL, p, p - 1);
+        const bool w_ = x > 0 && mm[p - 1];
+        if (w_ && (p & 63) == 0) uf_union(LL, p, p - 1);
         if (y > 0) {
-            if (mm[p - W]) uf_union(LL, p, p - W);
-            if (x > 0 && mm[p - W - 1]) uf_union(LL, p, p - W - 1);
-            if (x < W - 1 && mm[p - W + 1]) uf_union(LL, p, p - W + 1);
+            const bool n_ = mm[p - W], nw = x > 0 && mm[p - W - 1], ne = x < W - 1 && mm[p - W + 1];
+            if (n_) { if (!(w_ && nw)) uf_union(LL, p, p - W); }
+            else {
+                if (nw && !w_) uf_union(LL, p, p - W - 1);
+                if (ne) uf_union(LL, p, p - W + 1);
+            }
         }
     }
 }
@@ -112,8 +133,15 @@ __global__ void region_stats_kernel(const int *__restrict__ L, int H, int W, int
     const int *LL = L + base;
     IMG_LOOP(p, H * W) {
         const int l = LL[p];
+        // area: the lanes that share the first active lane's label add once (blob interiors: one atomic per wave)
+        const unsigned long long act = __ballot(l >= 0);
+        if (!act) continue;
+        const int lead = __ffsll((long long)act) - 1;
+        const int l0 = __shfl(l, lead);
+        const unsigned long long same = __ballot(l == l0);
         if (l < 0) continue;
-        atomicAdd(&area[base + l], 1);
+        if (l == l0) { if ((p & 63) == lead) atomicAdd(&area[base + l0], __popcll(same)); }
+        else atomicAdd(&area[base + l], 1);
         const int y = p / W, x = p - y * W;
         if (!is_border(LL, H, W, y, x, l)) continue;
         const int code = 1 + 2 * (is_border(LL, H, W, y - 1, x, l) + is_border(LL, H, W, y + 1, x, l) + is_border(LL, H, W, y, x - 1, l) + is_border(LL, H, W, y, x + 1, l)) +
@@ -250,37 +278,30 @@ __global__ void edt_cols_kernel(const uint8_t *__restrict__ m, int *__restrict__
     }
     if (zero) atomicOr(&any_zero[img], 1);
 }
-__global__ void edt_rows_kernel(const int *__restrict__ g, int H, int W, const int *__restrict__ any_zero, int *__restrict__ st,
-                                double *__restrict__ dist)
+// Row phase: dist2(y, x) = min over i of (x - i)^2 + g(y, i)^2 -- the lower envelope Meijster's scan builds, evaluated
+// directly: one block per row, g^2 of the row in LDS, every thread scans outward from its own column and stops once the
+// horizontal offset alone exceeds the best value (exact integers, so the minimum is the same number).
+__global__ __launch_bounds__(256) void edt_rows_kernel(const int *__restrict__ g, int H, int W, const int *__restrict__ any_zero,
+                                                       double *__restrict__ dist)
 {
-    const int img = blockIdx.y;
-    const int y = blockIdx.x * blockDim.x + threadIdx.x;
-    if (y >= H) return;
+    extern __shared__ long long g2[];           // [W]
+    const int img = blockIdx.y, y = blockIdx.x;
     double *dd = dist + ((size_t)img * H + y) * W;
     if (!any_zero[img]) {     // scipy quirk without background: distance to the virtual pixel (-1, 0)
-        for (int x = 0; x < W; x++) dd[x] = sqrt((double)((long long)(y + 1) * (y + 1) + (long long)x * x));
+        for (int x = threadIdx.x; x < W; x += 256) dd[x] = sqrt((double)((long long)(y + 1) * (y + 1) + (long long)x * x));
         return;
     }
     const int *gr = g + ((size_t)img * H + y) * W;
-    int *s = st + ((size_t)img * H + y) * 2 * W, *t = s + W;
-    auto f = [&](int x, int i) -> long long { const long long gi = gr[i]; return (long long)(x - i) * (x - i) + gi * gi; };
-    auto sep = [&](int i, int u) -> long long {
-        const long long gu = gr[u], gi = gr[i];
-        return ((long long)u * u - (long long)i * i + gu * gu - gi * gi) / (2 * (long long)(u - i));
-    };
-    int q = 0;
-    s[0] = 0; t[0] = 0;
-    for (int u = 1; u < W; u++) {
-        while (q >= 0 && f(t[q], s[q]) > f(t[q], u)) q--;
-        if (q < 0) { q = 0; s[0] = u; }
-        else {
-            const long long w = 1 + sep(s[q], u);
-            if (w < W) { q++; s[q] = u; t[q] = (int)w; }
+    for (int x = threadIdx.x; x < W; x += 256) { const long long v = gr[x]; g2[x] = v * v; }
+    __syncthreads();
+    for (int x = threadIdx.x; x < W; x += 256) {
+        long long best = g2[x];
+        for (int d = 1; (long long)d * d < best && (x - d >= 0 || x + d < W); d++) {
+            const long long dd2 = (long long)d * d;
+            if (x - d >= 0) { const long long v = dd2 + g2[x - d]; best = v < best ? v : best; }
+            if (x + d < W) { const long long v = dd2 + g2[x + d]; best = v < best ? v : best; }
         }
-    }
-    for (int u = W - 1; u >= 0; u--) {
-        dd[u] = sqrt((double)f(u, s[q]));
-        if (u == t[q]) q--;
+        dd[x] = sqrt((double)best);
     }
 }
 
@@ -289,7 +310,8 @@ void launch_edt(const uint8_t *mask, int k, int H, int W, int *g, int *st, int *
 {
     hipMemsetAsync(any_zero, 0, k * sizeof(int), s);
     hipLaunchKernelGGL(edt_cols_kernel, dim3((W + 63) / 64, k), dim3(64), 0, s, mask, g, H, W, any_zero);
-    hipLaunchKernelGGL(edt_rows_kernel, dim3((H + 63) / 64, k), dim3(64), 0, s, g, H, W, any_zero, st, dist);
+    (void)st;
+    hipLaunchKernelGGL(edt_rows_kernel, dim3(H, k), dim3(256), (size_t)W * sizeof(long long), s, g, H, W, any_zero, dist);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -326,7 +348,7 @@ int filter_edt_dev(const double *pred, int k, int H, int W, int remove_isolated,
     hipLaunchKernelGGL(threshold_kernel, grid, blk, 0, s, pred, seg, npx);
     hipLaunchKernelGGL(median13_kernel, grid, blk, 0, s, seg, med, H, W);
     // labels of the median-filtered mask
-    hipLaunchKernelGGL(ccl_init_kernel, grid, blk, 0, s, med, ML, npx);
+    hipLaunchKernelGGL(ccl_init_kernel, grid, blk, 0, s, med, ML, H, W);
     hipLaunchKernelGGL(ccl_merge_kernel, grid, blk, 0, s, med, ML, H, W);
     hipLaunchKernelGGL(ccl_compress_kernel, grid, blk, 0, s, ML, npx);
     if (hipMemsetAsync(area, 0, n * sizeof(int) * 6, s) != hipSuccess) { set_error("morph: memset"); return -2; }   // area,n1,n2,n3,fork,drop
@@ -351,7 +373,7 @@ int filter_edt_dev(const double *pred, int k, int H, int W, int remove_isolated,
     }
     hipLaunchKernelGGL(zhang_done_kernel, dim3((k + 63) / 64), dim3(64), 0, s, chg + (size_t)(launches - 1) * k, done, k);
     // skeleton components, fork test, decision, filtered mask
-    hipLaunchKernelGGL(ccl_init_kernel, grid, blk, 0, s, skA, SL, npx);
+    hipLaunchKernelGGL(ccl_init_kernel, grid, blk, 0, s, skA, SL, H, W);
     hipLaunchKernelGGL(ccl_merge_kernel, grid, blk, 0, s, skA, SL, H, W);
     hipLaunchKernelGGL(ccl_compress_kernel, grid, blk, 0, s, SL, npx);
     hipLaunchKernelGGL(skel_fork_kernel, grid, blk, 0, s, skA, SL, H, W, fork);
