@@ -90,19 +90,27 @@ __global__ __launch_bounds__(64 * WM * WN, ((BM + BN) * 256 > 65536 ? 2 : WM * W
     const int srow = t >> 3;
     const int c4 = ((t & 7) ^ (srow & 7)) * 4;
     constexpr unsigned OOB = 0x80000000u;
+    // pointwise, stride 1: the stored pixel of output m is m itself -- no index arithmetic at all (these layers have
+    // K = Cin as small as 64, i.e. two chunks per tile, so a division-heavy prologue would show)
+    const bool flat = KS == 1 && a.stride == 1;
     auto stored_pixel = [&](int m) {     // linear index of the stored pixel that output pixel m is centred on
         const int n = m / (Ho * Wo);
         const int r = m - n * (Ho * Wo);
         const int yo = r / Wo;
         return (n * a.h + yo * a.stride) * a.w + (r - yo * Wo) * a.stride;
     };
-    const int p0 = __builtin_amdgcn_readfirstlane(stored_pixel(m0));
+    const int p0 = flat ? m0 : __builtin_amdgcn_readfirstlane(stored_pixel(m0));
     unsigned pv[NPA];       // voffset (bytes) of the staged pixel's channel group
     unsigned pm[NPA];       // mask of the taps that fall inside the image
 #pragma unroll
     for (int i = 0; i < NPA; i++) {
         const int m = m0 + i * RP + srow;
         const bool ok = m < M;
+        if (flat) {
+            pv[i] = (unsigned)((i * RP + srow) * a.Cin + c4) * 4u;
+            pm[i] = ok ? 1u : 0u;
+            continue;
+        }
         const int mm = ok ? m : m0;
         const int n = mm / (Ho * Wo);
         const int r = mm - n * (Ho * Wo);
