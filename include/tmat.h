@@ -42,6 +42,9 @@ int tmat_version(void);
  * `max_patches` bounds the UNet batch held in HBM at once (0 = default 400 = two 1024^2 images).
  */
 int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max_patches, tmat_handle *out);
+/* A handle without weights (device + stream only) for the entry points that need no model: tmat_zproj_*,
+ * tmat_filter_edt_batch, tmat_finish_batch.  Model entry points return TMAT_E_ARG on it. */
+int tmat_create_plain(int device_id, tmat_handle *out);
 void tmat_destroy(tmat_handle h);
 /* blocks until all work queued on the handle's stream is done */
 int tmat_sync(tmat_handle h);
@@ -166,6 +169,20 @@ int tmat_host_skeletonize(const uint8_t *mask, int H, int W, uint8_t *out);
 int tmat_host_medial_axis(const uint8_t *mask, int H, int W, uint8_t *skel, double *dist);
 int tmat_host_permutation(uint32_t seed, int n, uint32_t *out);
 int tmat_host_postprocess(const double *pred, int H, int W, int out_h, int out_w, float *field);
+
+/*
+ * Z projection of image stacks -- what scripts/compute_zproj.py:73-84 calls through proj_methods
+ * (fl_tissue_model_tools/zstacks.py): "fs" proj_focus_stacking (zstacks.py:153-189: cv2.GaussianBlur 5x5 sigma 0, then
+ * cv2.Laplacian(CV_64F, ksize 5), per pixel the value of the first slice with the strictly largest |Laplacian|),
+ * "min" / "max" (np.min / np.max, :222-249), "avg" (np.mean, :192-204), "med" (np.median, :207-219).
+ * stacks (n, Z, H, W) u16 (uint8 stacks are widened by the caller: the arithmetic is the same); out (n, H, W):
+ * uint16 for fs / min / max, float64 for avg / med.  tmat_zproj_batch takes host pointers and streams the stacks
+ * through the device in chunks; tmat_zproj_dev takes device pointers and is asynchronous on the handle's stream
+ * (chain it in front of tmat_analyze_batch_dev).
+ */
+enum { TMAT_ZPROJ_FS = 0, TMAT_ZPROJ_MIN = 1, TMAT_ZPROJ_MAX = 2, TMAT_ZPROJ_AVG = 3, TMAT_ZPROJ_MED = 4 };
+int tmat_zproj_batch(tmat_handle h, const uint16_t *stacks, int n, int Z, int H, int W, int method, void *out);
+int tmat_zproj_dev(tmat_handle h, const uint16_t *stacks_dev, int n, int Z, int H, int W, int method, void *out_dev);
 
 /*
  * Timing hook for bench.py's roofline line: accumulated HIP-event time (ms) and launch count of

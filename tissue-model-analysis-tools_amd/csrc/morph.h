@@ -15,4 +15,6 @@ void launch_edt(const uint8_t *mask, int k, int H, int W, int *g, int *st, int *
 size_t finish_workspace_bytes(int k, int H, int W, int oh, int ow);
 int finish_dev(const double *pred, const double *dist, const uint8_t *skel, int k, int H, int W, int oh, int ow, void *workspace,
                float *field_out, float *f255_out, hipStream_t s);
+// zproj_kernels.hip: Z projection of n stacks (n, Z, H, W) u16 device -> (n, H, W) u16 (fs / min / max) or f64 (avg / med)
+int zproj_dev(const uint16_t *stacks, int n, int Z, int H, int W, int method, void *out, hipStream_t s);
 }  // namespace tmat

@@ -249,6 +249,7 @@ extern "C" {
 int tmat_segment_batch(tmat_handle hd, const uint16_t *imgs, int n, int H, int W, double ds_ratio, double *pred)
 {
     Ctx *c = (Ctx *)hd;
+    if (c && !has_model(c)) { set_error("tmat_segment_batch: this handle has no model (tmat_create_plain)"); return TMAT_E_ARG; }
     if (!c || !imgs || !pred || n < 0 || H < 1 || W < 1) { set_error("tmat_segment_batch: bad argument"); return TMAT_E_ARG; }
     if (n == 0) return TMAT_OK;
     TMAT_HIP(hipSetDevice(c->device));
@@ -323,6 +324,46 @@ int tmat_finish_batch(tmat_handle hd, const double *pred, const double *dist, co
     return rc;
 }
 
+int tmat_zproj_dev(tmat_handle hd, const uint16_t *stacks_dev, int n, int Z, int H, int W, int method, void *out_dev)
+{
+    Ctx *c = (Ctx *)hd;
+    if (!c || !stacks_dev || !out_dev || n < 0 || Z < 1 || H < 1 || W < 1 || method < TMAT_ZPROJ_FS || method > TMAT_ZPROJ_MED) {
+        set_error("tmat_zproj_dev: bad argument");
+        return TMAT_E_ARG;
+    }
+    if (n == 0) return TMAT_OK;
+    TMAT_HIP(hipSetDevice(c->device));
+    const int rc = zproj_dev(stacks_dev, n, Z, H, W, method, out_dev, c->stream);
+    return rc == 0 ? TMAT_OK : rc == -1 ? TMAT_E_ARG : TMAT_E_HIP;
+}
+
+int tmat_zproj_batch(tmat_handle hd, const uint16_t *stacks, int n, int Z, int H, int W, int method, void *out)
+{
+    Ctx *c = (Ctx *)hd;
+    if (!c || !stacks || !out || n < 0 || Z < 1 || H < 1 || W < 1 || method < TMAT_ZPROJ_FS || method > TMAT_ZPROJ_MED) {
+        set_error("tmat_zproj_batch: bad argument");
+        return TMAT_E_ARG;
+    }
+    if (n == 0) return TMAT_OK;
+    TMAT_HIP(hipSetDevice(c->device));
+    const size_t npx = (size_t)H * W, per_in = (size_t)Z * npx * sizeof(uint16_t);
+    const size_t osz = (method == TMAT_ZPROJ_AVG || method == TMAT_ZPROJ_MED) ? sizeof(double) : sizeof(uint16_t);
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)1 << 30) / per_in));   // <= 1 GiB of stacks at a time
+    uint16_t *din = nullptr; void *dout = nullptr;
+    int rc = TMAT_OK;
+    if (!hip_ok(hipMalloc((void **)&din, (size_t)chunk * per_in), "hipMalloc") || !hip_ok(hipMalloc(&dout, (size_t)chunk * npx * osz), "hipMalloc")) rc = TMAT_E_HIP;
+    for (int i0 = 0; i0 < n && !rc; i0 += chunk) {
+        const int k = std::min(chunk, n - i0);
+        if (!hip_ok(hipMemcpyAsync(din, stacks + (size_t)i0 * Z * npx, (size_t)k * per_in, hipMemcpyHostToDevice, c->stream), "H2D")) { rc = TMAT_E_HIP; break; }
+        const int r = zproj_dev(din, k, Z, H, W, method, dout, c->stream);
+        if (r) { rc = r == -1 ? TMAT_E_ARG : TMAT_E_HIP; break; }
+        if (!hip_ok(hipMemcpyAsync((char *)out + (size_t)i0 * npx * osz, dout, (size_t)k * npx * osz, hipMemcpyDeviceToHost, c->stream), "D2H") ||
+            !hip_ok(hipStreamSynchronize(c->stream), "sync")) rc = TMAT_E_HIP;
+    }
+    hipFree(din); hipFree(dout);
+    return rc;
+}
+
 int tmat_postprocess_batch(tmat_handle, const double *pred, int n, int hh, int ww, int out_h, int out_w, float *field)
 {
     if (!pred || !field || n < 0 || hh < 1 || ww < 1 || out_h < 1 || out_w < 1) { set_error("tmat_postprocess_batch: bad argument"); return TMAT_E_ARG; }
@@ -346,6 +387,7 @@ int tmat_analyze_batch_dev(tmat_handle hd, const uint16_t *imgs_dev, int n, int 
                            int max_branch_length_px, int remove_isolated, int64_t first_index, tmat_row *rows)
 {
     Ctx *c = (Ctx *)hd;
+    if (c && !has_model(c)) { set_error("tmat_analyze_batch_dev: this handle has no model (tmat_create_plain)"); return TMAT_E_ARG; }
     if (!c || !imgs_dev || !rows || n < 0 || H < 1 || W < 1 || ds_width < 1) { set_error("tmat_analyze_batch_dev: bad argument"); return TMAT_E_ARG; }
     if (n == 0) return TMAT_OK;
     TMAT_HIP(hipSetDevice(c->device));
@@ -358,6 +400,7 @@ int tmat_analyze_batch(tmat_handle hd, const uint16_t *imgs, int n, int H, int W
                        int max_branch_length_px, int remove_isolated, int64_t first_index, tmat_row *rows)
 {
     Ctx *c = (Ctx *)hd;
+    if (c && !has_model(c)) { set_error("tmat_analyze_batch: this handle has no model (tmat_create_plain)"); return TMAT_E_ARG; }
     if (!c || !imgs || !rows || n < 0) { set_error("tmat_analyze_batch: bad argument"); return TMAT_E_ARG; }
     if (n == 0) return TMAT_OK;
     TMAT_HIP(hipSetDevice(c->device));

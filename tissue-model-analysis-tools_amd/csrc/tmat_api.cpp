@@ -331,6 +331,26 @@ extern "C" {
 const char *tmat_last_error(void) { return g_err.c_str(); }
 int tmat_version(void) { return 0x000100; }
 
+// A handle without a model: device + stream only, for the entry points that need no weights (tmat_zproj_*,
+// tmat_filter_edt_batch, tmat_finish_batch).  Model entry points refuse it.
+int tmat_create_plain(int device_id, tmat_handle *out)
+{
+    if (!out) { set_error("tmat_create_plain: null argument"); return TMAT_E_ARG; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("tmat_create_plain: no HIP device available (libtmat_hip has no CPU fallback)");
+        return TMAT_E_HIP;
+    }
+    if (device_id < 0 || device_id >= ndev) { set_error("tmat_create_plain: bad device id"); return TMAT_E_ARG; }
+    TMAT_HIP(hipSetDevice(device_id));
+    Ctx *c = new Ctx();
+    c->device = device_id;
+    if (!hip_ok(hipStreamCreate(&c->stream), "hipStreamCreate")) { tmat_destroy((tmat_handle)c); return TMAT_E_HIP; }
+    *out = (tmat_handle)c;
+    return TMAT_OK;
+}
+
 int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max_patches, tmat_handle *out)
 {
     if (!out || !weights_blob) { set_error("tmat_create: null argument"); return TMAT_E_ARG; }
@@ -450,6 +470,7 @@ int tmat_sync(tmat_handle h)
 int tmat_unet_predict(tmat_handle h, const float *x, int n, float *y)
 {
     Ctx *c = (Ctx *)h;
+    if (c && !has_model(c)) { set_error("tmat_unet_predict: this handle has no model (tmat_create_plain)"); return TMAT_E_ARG; }
     if (!c || !x || !y || n < 0) { set_error("tmat_unet_predict: bad argument"); return TMAT_E_ARG; }
     TMAT_HIP(hipSetDevice(c->device));
     const size_t per = (size_t)c->patch * c->patch;
@@ -467,6 +488,7 @@ int tmat_unet_predict(tmat_handle h, const float *x, int n, float *y)
 int tmat_predict_smooth(tmat_handle h, const float *x, int n, int hh, int ww, double *pred)
 {
     Ctx *c = (Ctx *)h;
+    if (c && !has_model(c)) { set_error("tmat_predict_smooth: this handle has no model (tmat_create_plain)"); return TMAT_E_ARG; }
     if (!c || !x || !pred || n < 0 || hh <= 0 || ww <= 0) { set_error("tmat_predict_smooth: bad argument"); return TMAT_E_ARG; }
     if (n == 0) return TMAT_OK;
     TMAT_HIP(hipSetDevice(c->device));

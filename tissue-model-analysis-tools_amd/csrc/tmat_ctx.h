@@ -128,4 +128,6 @@ inline double numpy_pairwise_sum(const double *a, long n)
     return numpy_pairwise_sum(a, n2) + numpy_pairwise_sum(a + n2, n - n2);
 }
 
+// handles made by tmat_create_plain carry no model
+inline bool has_model(const Ctx *c) { return c && !c->up.empty(); }
 }  // namespace tmat

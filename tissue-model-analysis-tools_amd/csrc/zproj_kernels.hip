@@ -1,0 +1,174 @@
+// Z projections of image stacks for gfx950 (MI355X): focus stacking, min, max, mean, median.
+//
+// Reference: fl_tissue_model_tools/zstacks.py:134-249 (proj_focus_stacking, proj_avg, proj_med, proj_max, proj_min),
+// driven by scripts/compute_zproj.py:73-84.  Arithmetic contract (shared with oracle/zproj.py, compared bit-exactly):
+//   blur  B = (sum_{ij} g_i g_j I(reflect101) + 128) >> 8,  g = [1, 4, 6, 4, 1]        (cv2.GaussianBlur(5x5, sigma 0), fixed point)
+//   focus L = | sum_{ij} (g_i d_j + d_i g_j) B(reflect101) |, d = [1, 0, -2, 0, 1]      (cv2.Laplacian(CV_64F, ksize 5))
+//   projection = value of the first slice with the strictly largest L.
+// Everything is integer arithmetic below 2^24, so it is exact in OpenCV's float work type and here.
+//
+// HBM-bound: every input sample is read once per tile that needs it (72 x 72 staged for 64 x 64 outputs, 1.27x through
+// L2), the projection is written once; the blurred slice and the focus measure never leave LDS / registers.
+// The two-stage integer filter chain costs about 45 VALU operations per pixel and slice, which bounds the kernel
+// before HBM does.
+#include "tmat_internal.h"
+#include "morph.h"
+#include "../../include/tmat.h"
+
+#include <cstdint>
+
+namespace tmat {
+
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    const int p = 2 * (n - 1);
+    i %= p;
+    if (i < 0) i += p;
+    return i < n ? i : p - i;
+}
+
+constexpr int ZT = 64;              // output tile (64 x 64)
+constexpr int ZI = ZT + 8;          // staged input tile (halo 4)
+constexpr int ZB = ZT + 4;          // blurred tile (halo 2)
+constexpr int ZBS = ZB + 4;         // row stride of the blurred tile in LDS (8-byte aligned rows)
+
+// Two register-blocked stages per slice, both on 4 x 4 patches whose 8 x 8 source window is read from LDS with
+// 8-byte loads (one LDS read per output instead of one per tap), separable in registers:
+//   stage 1: input (72 x 72, reflect-101 gathered) -> blurred tile (68 x 68):  rows [1,4,6,4,1], columns [1,4,6,4,1], +128 >> 8
+//   stage 2: blurred -> focus measure (64 x 64): rows with g and with d = [1,0,-2,0,1], columns d (on the g rows) + g (on the d rows)
+// and the running arg-max over slices lives in registers (16 outputs per thread).
+__device__ __forceinline__ void load8(const uint16_t *p, unsigned v[8])
+{
+    const uint2 a = *reinterpret_cast<const uint2 *>(p), b = *reinterpret_cast<const uint2 *>(p + 4);
+    v[0] = a.x & 0xffffu; v[1] = a.x >> 16; v[2] = a.y & 0xffffu; v[3] = a.y >> 16;
+    v[4] = b.x & 0xffffu; v[5] = b.x >> 16; v[6] = b.y & 0xffffu; v[7] = b.y >> 16;
+}
+
+__global__ __launch_bounds__(256) void zproj_focus_kernel(const uint16_t *__restrict__ stacks, int Z, int H, int W,
+                                                          uint16_t *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(8))) uint16_t in[ZI][ZI];
+    __shared__ __attribute__((aligned(8))) uint16_t bl[ZB][ZBS];
+    __shared__ int ry[ZI], rx[ZI];
+    const int t = threadIdx.x;
+    const int x0 = blockIdx.x * ZT, y0 = blockIdx.y * ZT;
+    const size_t npx = (size_t)H * W;
+    const uint16_t *st = stacks + (size_t)blockIdx.z * Z * npx;
+    if (t < ZI) { ry[t] = reflect101(y0 - 4 + t, H); rx[t] = reflect101(x0 - 4 + t, W); }
+    __syncthreads();
+    const int py = t >> 4, px = t & 15;                  // this thread's 4 x 4 output patch
+    int best[4][4];
+    unsigned val[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) { best[i][c] = -1; val[i][c] = 0; }
+    for (int z = 0; z < Z; z++) {
+        const uint16_t *sl = st + (size_t)z * npx;
+        for (int e = t; e < ZI * ZI; e += 256) {
+            const int iy = e / ZI, ix = e - iy * ZI;
+            in[iy][ix] = sl[(size_t)ry[iy] * W + rx[ix]];
+        }
+        __syncthreads();
+        // stage 1: 17 x 17 patches of the blurred tile
+        for (int q = t; q < (ZB / 4) * (ZB / 4); q += 256) {
+            const int qy = q / (ZB / 4), qx = q - qy * (ZB / 4);
+            unsigned hb[8][4];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                unsigned v[8];
+                load8(&in[4 * qy + r][4 * qx], v);
+#pragma unroll
+                for (int c = 0; c < 4; c++) hb[r][c] = v[c] + 4u * v[c + 1] + 6u * v[c + 2] + 4u * v[c + 3] + v[c + 4];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                unsigned b[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    b[c] = (hb[i][c] + 4u * hb[i + 1][c] + 6u * hb[i + 2][c] + 4u * hb[i + 3][c] + hb[i + 4][c] + 128u) >> 8;
+                *reinterpret_cast<uint2 *>(&bl[4 * qy + i][4 * qx]) = make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
+            }
+        }
+        __syncthreads();
+        // stage 2: this thread's patch of the focus measure, arg-max update
+        {
+            int hg[8][4], hd[8][4];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                unsigned v[8];
+                load8(&bl[4 * py + r][4 * px], v);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    hg[r][c] = (int)(v[c] + 4u * v[c + 1] + 6u * v[c + 2] + 4u * v[c + 3] + v[c + 4]);
+                    hd[r][c] = (int)v[c] - 2 * (int)v[c + 2] + (int)v[c + 4];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint2 cw = *reinterpret_cast<const uint2 *>(&in[4 * py + 4 + i][4 * px + 4]);      // centre input values
+                const unsigned cv[4] = {cw.x & 0xffffu, cw.x >> 16, cw.y & 0xffffu, cw.y >> 16};
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    int s = hg[i][c] - 2 * hg[i + 2][c] + hg[i + 4][c] + hd[i][c] + 4 * hd[i + 1][c] + 6 * hd[i + 2][c] + 4 * hd[i + 3][c] + hd[i + 4][c];
+                    s = s < 0 ? -s : s;
+                    if (s > best[i][c]) { best[i][c] = s; val[i][c] = cv[c]; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int y = y0 + 4 * py + i, x = x0 + 4 * px + c;
+            if (y < H && x < W) out[(size_t)blockIdx.z * npx + (size_t)y * W + x] = (uint16_t)val[i][c];
+        }
+}
+
+// min / max / mean / median along z: one thread per pixel
+constexpr int ZMED_MAX = 64;
+__global__ __launch_bounds__(256) void zproj_reduce_kernel(const uint16_t *__restrict__ stacks, int Z, size_t npx, int method,
+                                                           uint16_t *__restrict__ out16, double *__restrict__ out64)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npx) return;
+    const uint16_t *st = stacks + (size_t)blockIdx.y * Z * npx + p;
+    const size_t o = (size_t)blockIdx.y * npx + p;
+    if (method == TMAT_ZPROJ_MIN || method == TMAT_ZPROJ_MAX) {
+        unsigned m = st[0];
+        for (int z = 1; z < Z; z++) { const unsigned v = st[(size_t)z * npx]; m = method == TMAT_ZPROJ_MIN ? (v < m ? v : m) : (v > m ? v : m); }
+        out16[o] = (uint16_t)m;
+    } else if (method == TMAT_ZPROJ_AVG) {
+        double s = 0.0;                                  // integers: exact in any order (np.mean, f64 accumulator)
+        for (int z = 0; z < Z; z++) s += (double)st[(size_t)z * npx];
+        out64[o] = s / (double)Z;
+    } else {                                             // median (np.median: mean of the middle value(s))
+        uint16_t v[ZMED_MAX];
+        for (int z = 0; z < Z; z++) {                    // insertion sort
+            const uint16_t x = st[(size_t)z * npx];
+            int i = z;
+            while (i > 0 && v[i - 1] > x) { v[i] = v[i - 1]; i--; }
+            v[i] = x;
+        }
+        out64[o] = (Z & 1) ? (double)v[Z / 2] : ((double)v[Z / 2 - 1] + (double)v[Z / 2]) / 2.0;
+    }
+}
+
+int zproj_dev(const uint16_t *stacks, int n, int Z, int H, int W, int method, void *out, hipStream_t s)
+{
+    if (method == TMAT_ZPROJ_FS) {
+        hipLaunchKernelGGL(zproj_focus_kernel, dim3((W + ZT - 1) / ZT, (H + ZT - 1) / ZT, n), dim3(256), 0, s, stacks, Z, H, W, (uint16_t *)out);
+    } else {
+        if (method == TMAT_ZPROJ_MED && Z > ZMED_MAX) { set_error("zproj: median supports at most 64 slices"); return -1; }
+        const size_t npx = (size_t)H * W;
+        hipLaunchKernelGGL(zproj_reduce_kernel, dim3((unsigned)((npx + 255) / 256), n), dim3(256), 0, s, stacks, Z, npx, method,
+                           (uint16_t *)out, (double *)out);
+    }
+    if (hipGetLastError() != hipSuccess) { set_error("zproj: kernel launch failed"); return -2; }
+    return 0;
+}
+
+}  // namespace tmat

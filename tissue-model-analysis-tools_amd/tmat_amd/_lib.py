@@ -39,6 +39,7 @@ def lib():
     L.tmat_last_error.restype = C.c_char_p
     L.tmat_version.restype = i
     L.tmat_create.argtypes = [i, vp, sz, i, C.POINTER(vp)]
+    L.tmat_create_plain.argtypes = [i, C.POINTER(vp)]
     L.tmat_destroy.argtypes = [vp]
     L.tmat_destroy.restype = None
     L.tmat_sync.argtypes = [vp]
@@ -48,6 +49,8 @@ def lib():
     L.tmat_postprocess_batch.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.tmat_filter_edt_batch.argtypes = [vp, vp, i, i, i, vp, vp]
     L.tmat_finish_batch.argtypes = [vp, vp, vp, vp, i, i, i, i, i, vp, vp]
+    L.tmat_zproj_batch.argtypes = [vp, vp, i, i, i, i, i, vp]
+    L.tmat_zproj_dev.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.tmat_dmt_graph.argtypes = [vp, vp, i, i, f, f, vp, i, vp, i, C.POINTER(i), C.POINTER(i)]
     L.tmat_morse_stats.argtypes = [vp, i, vp, i, i, i, i, i, i, i, vp, C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                    C.POINTER(C.c_double), vp, i]
@@ -67,8 +70,9 @@ def lib():
 
 
 EXPORTS = [
-    "tmat_last_error", "tmat_version", "tmat_create", "tmat_destroy", "tmat_sync", "tmat_unet_predict",
-    "tmat_predict_smooth", "tmat_segment_batch", "tmat_postprocess_batch", "tmat_filter_edt_batch", "tmat_finish_batch", "tmat_dmt_graph", "tmat_morse_stats",
+    "tmat_last_error", "tmat_version", "tmat_create", "tmat_create_plain", "tmat_destroy", "tmat_sync", "tmat_unet_predict",
+    "tmat_predict_smooth", "tmat_segment_batch", "tmat_postprocess_batch", "tmat_filter_edt_batch", "tmat_finish_batch", "tmat_zproj_batch", "tmat_zproj_dev",
+    "tmat_dmt_graph", "tmat_morse_stats",
     "tmat_analyze_batch_dev", "tmat_analyze_batch", "tmat_dev_alloc", "tmat_dev_free", "tmat_dev_upload",
     "tmat_prof_enable", "tmat_prof_read", "tmat_host_lanczos4_u16", "tmat_host_rescale01_u16",
     "tmat_host_rescale255_f32", "tmat_host_filter_mask", "tmat_host_skeletonize", "tmat_host_medial_axis",
@@ -89,10 +93,14 @@ def ptr(a: np.ndarray):
 class Handle:
     """Owns one tmat_handle (one HIP device + stream + resident weights)."""
 
-    def __init__(self, weights_blob: bytes, device_id: int = 0, max_patches: int = 0):
+    def __init__(self, weights_blob: "bytes | None", device_id: int = 0, max_patches: int = 0):
+        """weights_blob None: a handle without a model (tmat_create_plain), enough for zproj / filter_edt / finish"""
         L = lib()
         self._h = C.c_void_p()
         self._blob = weights_blob
+        if weights_blob is None:
+            check(L.tmat_create_plain(device_id, C.byref(self._h)), "tmat_create_plain")
+            return
         buf = (C.c_char * len(weights_blob)).from_buffer_copy(weights_blob)
         check(L.tmat_create(device_id, C.cast(buf, C.c_void_p), len(weights_blob), max_patches, C.byref(self._h)),
               "tmat_create")
@@ -148,6 +156,21 @@ class Handle:
         check(lib().tmat_finish_batch(self._h, ptr(pred), ptr(dist), ptr(skel), n, pred.shape[1], pred.shape[2], out_shape[0],
                                       out_shape[1], ptr(f), ptr(f255)), "tmat_finish_batch")
         return f, f255
+
+    ZPROJ_METHODS = {"fs": 0, "min": 1, "max": 2, "avg": 3, "med": 4}
+
+    def zproj(self, stacks, method="fs"):
+        """GPU Z projection of (n, Z, H, W) uint8/uint16 stacks -> (n, H, W); dtype as zstacks.py returns it
+        (input dtype for fs / min / max, float64 for avg / med)"""
+        stacks = np.asarray(stacks)
+        if stacks.ndim != 4 or stacks.dtype not in (np.uint8, np.uint16):
+            raise ValueError("zproj: expected (n, Z, H, W) uint8 or uint16 stacks")
+        m = self.ZPROJ_METHODS[method]
+        a = np.ascontiguousarray(stacks, np.uint16)
+        n, Z, H, W = a.shape
+        out = np.empty((n, H, W), np.float64 if m >= 3 else np.uint16)
+        check(lib().tmat_zproj_batch(self._h, ptr(a), n, Z, H, W, m, ptr(out)), "tmat_zproj_batch")
+        return out.astype(stacks.dtype) if m < 3 else out
 
     def prof_enable(self, on=True):
         check(lib().tmat_prof_enable(self._h, int(on)), "tmat_prof_enable")
