@@ -63,3 +63,28 @@ def test_script_error_exits(tmp_path):
     assert r.returncode == 1 and "image-width-microns" in r.stdout
     r = run([str(tmp_path / "in"), str(tmp_path / "o"), "-c", str(tmp_path / "nope.json")])
     assert r.returncode == 1 and "Config file" in r.stdout
+
+
+def test_script_takes_the_width_from_tiff_metadata(tmp_path, handle):
+    """no --image-width-microns: width = columns x PhysicalPixelSizes.X of each file (compute_branches.py:184-212);
+    files with different pixel sizes are analysed with their own pixel parameters"""
+    from PIL import Image, TiffImagePlugin
+    from tmat_amd import branches, synth
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir()
+    imgs = {f"m_{i}": synth.synth_image(10 + i, 512, n_vessels=12, scale=1.0) for i in range(2)}
+    px_um = {"m_0": 0.9765625, "m_1": 1.5}               # 512 px -> 500 um and 768 um
+    for k, v in imgs.items():
+        info = TiffImagePlugin.ImageFileDirectory_v2()
+        info[270] = ('<OME><Image><Pixels DimensionOrder="XYZCT" SizeX="512" SizeY="512" '
+                     f'PhysicalSizeX="{px_um[k]}" PhysicalSizeY="{px_um[k]}" Type="uint16"/></Image></OME>')
+        Image.fromarray(v).save(ind / f"{k}.tif", tiffinfo=info)
+    r = run([str(ind), str(outd)])
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = read_csv(outd / "branching_analysis.csv")[1:]
+    cfg = dict(graph_thresh_1=5, graph_thresh_2=10, graph_smoothing_window=12, min_branch_length=12)
+    for got, k in zip(rows, sorted(imgs)):
+        width = 512 * px_um[k]
+        w = branches.analyze_batch(handle, imgs[k][None], cfg, width)[0]
+        assert got[0] == k and int(got[1]) == w[1]
+        assert float(got[2]) == pytest.approx(branches.pixels_to_microns(w[2], 384, width), rel=1e-12)

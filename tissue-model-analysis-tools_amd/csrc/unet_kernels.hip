@@ -37,7 +37,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 template <int BM, int BN, int WM, int WN, int KS, bool RELU>
-__global__ __launch_bounds__(64 * WM * WN, ((BM + BN) * 256 > 65536 ? 2 : WM * WN == 8 ? 4 : 2)) void conv_mfma_kernel(ConvArgs a, int M, int Ho, int Wo, int nMt, int nNt)
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 > 65536 ? 2 : WM * WN == 8 ? 4 : 2)) void conv_mfma_kernel(ConvArgs a, int M, int Ho, int Wo, int nMt, int nNt)
 {
     // KS (1, 2 or 3) is a template parameter so that the 3x3 and the pointwise instantiations are distinct kernels
     // (distinct names in rocprofv3 traces: the 3x3 <128,128,2,2,3,*> instantiations are the dominant kernel).
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((BM + BN) * 256 > 65536 ? 2 : WM * W
     // (2i + py, 2j + px) only sees the 2x2 stored pixels (i + py - 1 + {0,1}, j + px - 1 + {0,1}), with the 3x3 taps that
     // fall on the same stored pixel pre-summed per parity class (weights [class][tap][Cout][Cin], class = blockIdx.y,
     // M enumerates the stored pixels).  4/9 of the multiply-adds of the as-written form.
-    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves");
+    static_assert(WM * WN == 4 || WM * WN == 8 || WM * WN == 16, "4, 8 or 16 waves");
     constexpr int NT = 64 * WM * WN;                 // threads
     constexpr int RP = NT / 8;                       // rows per DMA pass: NT lanes x 16 B = RP rows of 128 B
     constexpr int KC = 32;
@@ -356,6 +356,9 @@ static void launch_conv_cfg(const ConvArgs &a, int M, int Ho, int Wo, hipStream_
 #define TMAT_WM 4       // waves per block = TMAT_WM x TMAT_WN: 8 waves (32 x 64 outputs each) measured 2-4 % faster than 2 x 2
 #define TMAT_WN 2
 #endif
+#ifndef TMAT_BM
+#define TMAT_BM 128
+#endif
 #ifndef TMAT_64_BM
 #define TMAT_64_BM 128  // tile of the Cout = 64 layers
 #define TMAT_64_WM 4
@@ -376,7 +379,7 @@ bool launch_conv(const ConvArgs &a, hipStream_t s)
     const int M = (int)Mll;
     if (!a.zeros || a.Cin > 2048) { set_error("launch_conv: missing zero row or Cin > 2048"); return false; }
     if (a.Cout % 128 == 0)
-        launch_conv_cfg<128, 128, TMAT_WM, TMAT_WN>(a, M, Ho, Wo, s);
+        launch_conv_cfg<TMAT_BM, 128, TMAT_WM, TMAT_WN>(a, M, Ho, Wo, s);
     else
         launch_conv_cfg<TMAT_64_BM, 64, TMAT_64_WM, TMAT_64_WN>(a, M, Ho, Wo, s);
     return true;

@@ -10,7 +10,8 @@ scripts/compute_branches.py (2-D branch): same positional arguments, flags, conf
 Differences (documented in INTEGRATION.md): images are analysed in batches on the GPU (one process
 per GPU under torch.distributed.run; rows are gathered over RCCL and rank 0 writes the CSV);
 Z-stack inputs, --detect-well and the PNG visualisations are outside the accelerated path;
---image-width-microns (or the config key) is required because image metadata is not parsed.
+without --image-width-microns (or the config key) the width comes from OME / ImageJ TIFF metadata
+(tmat_amd/helper.py), as in the reference.
 """
 import argparse
 import csv
@@ -129,11 +130,8 @@ def main(args=None):
     if not paths:
         print(f"{FAIL}No images found in {in_root}", flush=True)
         sys.exit(1)
-    if config.get("image_width_microns") is None:
-        print(f"{FAIL} The --image-width-microns parameter was not specified (image metadata is not parsed by the "
-              "accelerated path). Specify it and try again. Exiting...", flush=True)
-        sys.exit(1)
-
+    # image_width_microns: the option / config key, else per image from the file's metadata (reference
+    # compute_branches.py:184-212: img.shape[-1] * PhysicalPixelSizes.X), else the reference's failure message
     from tmat_amd import branches, distributed, models
     ws, rank, local_rank = distributed.world()
     if ws > 1:
@@ -149,19 +147,30 @@ def main(args=None):
     mine = [ids[i] for i in distributed.shard_indices(len(ids), rank, ws)]
     grid = branches.threshold_grid(config)
     results = {suffix: [] for _, suffix in grid}
-    # batch images of equal shape
-    by_shape = {}
+    # batch images of equal shape and physical width
+    from tmat_amd import helper
+    groups = {}
     for gi, img_id in enumerate(mine):
         print(f"Analyzing {img_id}...", flush=True)
         img = load_image_2d(paths[img_id], args.channel, args.time)
-        by_shape.setdefault(img.shape, []).append((ids.index(img_id), img))
-    for shape, items in by_shape.items():
+        width_um = config.get("image_width_microns")
+        if width_um is None:
+            px = helper.physical_pixel_sizes(paths[img_id]).X
+            if px is None:
+                print(f"{FAIL} The --image-width-microns parameter was not specified, and the pixel to micron conversion "
+                      f"factor was not found in the image metadata ({img_id}). Specify --image-width-microns and try again. "
+                      "Exiting...", flush=True)
+                sys.exit(1)
+            width_um = img.shape[-1] * px
+        groups.setdefault((img.shape, float(width_um)), []).append((ids.index(img_id), img))
+    for (shape, width_um), items in groups.items():
         batch = np.stack([im for _, im in items])
         for cfg, suffix in grid:
-            rows = branches.analyze_batch(model.handle, batch, config, config["image_width_microns"], model.ds_ratio,
+            rows = branches.analyze_batch(model.handle, batch, config, width_um, model.ds_ratio,
                                           thresh=(cfg["thresh1"], cfg["thresh2"]))
+            um = lambda px: branches.pixels_to_microns(px, DOWNSAMPLE_WIDTH, width_um)
             for (gidx, _), r in zip(items, rows):
-                results[suffix].append((gidx, r[1], r[2], r[3]))
+                results[suffix].append((gidx, r[1], um(r[2]), um(r[3])))
     created = set()
     for _, suffix in grid:
         rows = distributed.gather_rows(results[suffix])
@@ -176,9 +185,8 @@ def main(args=None):
         created.add(str(output_file))
         with open(output_file, "a", encoding="utf-16") as f:
             wr = csv.writer(f, lineterminator="\n")
-            for gidx, cnt, tot_px, avg_px in rows:
-                um = lambda px: branches.pixels_to_microns(px, DOWNSAMPLE_WIDTH, config["image_width_microns"])
-                wr.writerow([ids[gidx], cnt, um(tot_px), um(avg_px)])
+            for gidx, cnt, tot_um, avg_um in rows:
+                wr.writerow([ids[gidx], cnt, tot_um, avg_um])
         print(f"Results saved to {output_file}.", flush=True)
     if rank == 0:
         config["time"], config["channel"] = getattr(args, "time", None), getattr(args, "channel", None)
