@@ -90,14 +90,18 @@ static int enqueue_segment(Ctx *c, const uint16_t *imgs_dev, int k, int slot)
 // Two-stream form used by tmat_analyze_batch*: the memory-bound front half of pass p+1 (Lanczos, rescale, tile
 // gather, UNet down path) runs on stream2 while the MFMA-bound back half of pass p (UNet up path, final conv, blend,
 // D2H) runs on the main stream.
+static bool use_one_stream()
+{
+    static const bool one = [] { const char *e = getenv("TMAT_STREAMS"); return !(e && atoi(e) == 2); }();
+    return one;
+}
 static int enqueue_front(Ctx *c, const uint16_t *imgs_dev, int k, int slot, const TileGeom &g)
 {
     PassBuf &b = c->pass;
     // Default: both halves on the main stream.  TMAT_STREAMS=2 puts this half on the second stream; measured +1.8 %
     // images/s, but every kernel of the MFMA half then shares the CUs with a memory-bound one and its own duration
     // (the roofline measurement) stretches by 20 %, so the overlap is opt-in.
-    static const bool one_stream = [] { const char *e = getenv("TMAT_STREAMS"); return !(e && atoi(e) == 2); }();
-    hipStream_t s = one_stream ? c->stream : c->stream2;
+    hipStream_t s = use_one_stream() ? c->stream : c->stream2;
     launch_lanczos(imgs_dev, k, b.H, b.W, b.h, b.w, b.xi, b.xc, b.yi, b.yc, b.tmp, b.small, s);
     launch_rescale01(b.small, k, (size_t)b.h * b.w, b.mn, b.mx, b.x, s);
     float *mn = (float *)c->scratch, *mx = mn + k;
@@ -216,6 +220,8 @@ static int analyze_dev(Ctx *c, const uint16_t *imgs_dev, int n, int H, int W, do
     PassJob jobs[2];
     auto cnt = [&](int p) { return std::min(K, n - p * K); };
     auto img_at = [&](int p) { return imgs_dev + (size_t)p * K * H * W; };
+    // the caller may have queued work that produces the images on the main stream (tmat_zproj_dev, tmat_dev_upload)
+    if (!use_one_stream() && !hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return TMAT_E_HIP;
     rc = enqueue_front(c, img_at(0), cnt(0), 0, g);
     if (!rc) rc = enqueue_back(c, cnt(0), 0, g);
     if (!rc && P > 1) rc = enqueue_front(c, img_at(1), cnt(1), 1, g);
