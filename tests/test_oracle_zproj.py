@@ -3,6 +3,7 @@ kernels, its defining properties, and the host-side stack discovery of tmat_amd/
 
 OpenCV is absent here and the reference holds no fixture for compute_zproj, so these tests pin the restatement to the
 published kernels (parity unpinned against cv2 itself; see oracle/zproj.py)."""
+import json
 import os
 import sys
 from pathlib import Path
@@ -52,6 +53,38 @@ def test_focus_stacking_properties():
     assert np.array_equal(oz.proj_focus_stacking(np.moveaxis(st, 0, 2), axis=2), oz.proj_focus_stacking(st))
 
 
+GOLD = json.loads((Path(__file__).parent / "golden" / "zstacks.json").read_text())
+
+
+@pytest.mark.parametrize("name", sorted(GOLD["layouts"]))
+def test_discovery_matches_reference_goldens(tmp_path, name):
+    """tests/golden/zstacks.json was produced by the reference's own zstacks.py (tools/make_goldens.py zstacks)"""
+    from tmat_amd import zstacks as zs
+    rec = GOLD["layouts"][name]
+    for f in rec["files"]:
+        (tmp_path / f).parent.mkdir(parents=True, exist_ok=True)
+        (tmp_path / f).write_bytes(b"x")
+    if "error" in rec:
+        with pytest.raises(zs.ZStackInputException):
+            zs.find_zstack_image_sequences(str(tmp_path))
+    else:
+        got = zs.find_zstack_image_sequences(str(tmp_path))
+        assert {k: [os.path.relpath(p, tmp_path).replace(os.sep, "/") for p in v] for k, v in got.items()} == rec["sequences"]
+    if "files_as_stacks" in rec:
+        assert {k: os.path.relpath(v, tmp_path) for k, v in zs.find_zstack_files(str(tmp_path)).items()} == rec["files_as_stacks"]
+
+
+def test_clean_ids_and_reductions_match_reference_goldens():
+    from tmat_amd import zstacks as zs
+    for case in GOLD["clean_ids"]:
+        assert zs.clean_zstack_ids(list(case["in"])) == case["out"], case
+    for rec in GOLD["proj"].values():
+        st = np.array(rec["stack"], np.uint16)
+        for m in ("min", "max", "avg", "med"):
+            got = getattr(oz, "proj_" + m)(st)
+            assert str(got.dtype) == rec[m]["dtype"] and np.array_equal(got, np.array(rec[m]["values"])), m
+
+
 def test_discovery_of_image_sequences_and_files(tmp_path):
     from tmat_amd import zstacks as zs
     d = tmp_path / "seq"
@@ -70,7 +103,6 @@ def test_discovery_of_image_sequences_and_files(tmp_path):
             (d2 / well / f"img_Z{z:02d}.png").write_bytes(b"x")
     got = zs.find_zstack_image_sequences(str(d2))
     assert len(got) == 2 and all(len(v) == 3 for v in got.values())
-    assert all("/" not in k and "\\" not in k for k in got)
     # duplicated slice numbers are refused
     d3 = tmp_path / "dup"
     d3.mkdir()
@@ -84,7 +116,6 @@ def test_discovery_of_image_sequences_and_files(tmp_path):
     (d4 / "s1.tif").write_bytes(b"x")
     (d4 / "s2.tiff").write_bytes(b"x")
     assert sorted(zs.find_zstack_files(str(d4))) == ["s1", "s2"]
-    assert zs.clean_zstack_ids(["exp/exp_a", "exp/exp_b"]) == ["exp_a", "exp_b"] or len(set(zs.clean_zstack_ids(["exp/exp_a", "exp/exp_b"]))) == 2
 
 
 def test_zproj_script_argument_surface():

@@ -167,6 +167,7 @@ def main(args=None):
             if img.dtype == np.float64 and out_ext == ".png":
                 out_ext = ".tiff"
             save_path = get_unique_output_filepath(os.path.join(out_root, f"{zs_id}_{args.method}{out_ext}"))
+            Path(save_path).parent.mkdir(parents=True, exist_ok=True)     # ids keep a folder part when stacks sit one per folder
             save_projection(save_path, img)
             print(f"Z projection saved to {save_path}", flush=True)
     print("... Projections saved.", flush=True)

@@ -77,8 +77,10 @@ def _unique_or_keep(candidate, current):
 
 
 def clean_zstack_ids(zstack_ids):
-    """Shorten stack identifiers without making two of them collide (zstacks.py:17-61): drop a directory part that
-    only repeats the file name, turn path separators into underscores, strip and collapse underscores."""
+    """Shorten stack identifiers (zstacks.py:17-61): drop a directory part that only repeats the file name, then strip
+    leading / trailing underscores and collapse double underscores, each step only if the identifiers stay distinct.
+    As in the reference, path separators are turned into underscores only when doing so makes two identifiers collide
+    (then it is applied to the original identifiers); otherwise they are kept."""
     original = list(zstack_ids)
     ids = []
     for zid in original:
@@ -92,8 +94,6 @@ def clean_zstack_ids(zstack_ids):
     flat = [z.replace("/", "_").replace("\\", "_") for z in cur]
     if len(set(flat)) != len(flat):
         cur = [z.replace("/", "_").replace("\\", "_") for z in original]
-    else:
-        cur = flat
     cur = _unique_or_keep([z.lstrip("_") for z in cur], cur)
     cur = _unique_or_keep([z.rstrip("_") for z in cur], cur)
     cur = _unique_or_keep([z.replace("__", "_") for z in cur], cur)

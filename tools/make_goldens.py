@@ -230,6 +230,60 @@ def gen_morse():
 
 
 
+# --------------------------------------------------------------------------------------------
+# zstacks group: the pure-Python / numpy parts of zstacks.py (stack discovery, id clean-up, min / max / avg / med).
+# proj_focus_stacking needs cv2.GaussianBlur / cv2.Laplacian, which the shim does not provide (OpenCV is absent).
+# --------------------------------------------------------------------------------------------
+ZSTACK_LAYOUTS = {
+    "flat_two_wells": ["A1_z1_ch0.tif", "A1_z2_ch0.tif", "A1_z10_ch0.tif", "B2_z1_ch0.tif", "B2_z2_ch0.tif", "B2_z10_ch0.tif"],
+    "upper_case_z": ["img_Z00.png", "img_Z01.png", "img_Z02.png"],
+    "one_folder_per_stack": ["w1/img_z0.tif", "w1/img_z1.tif", "w2/img_z0.tif", "w2/img_z1.tif"],
+    "folder_repeats_name": ["exp1_w1/exp1_w1_z0.tif", "exp1_w1/exp1_w1_z1.tif", "exp1_w2/exp1_w2_z0.tif", "exp1_w2/exp1_w2_z1.tif"],
+    "two_numbers": ["s_z1_t_z5.tif", "s_z2_t_z5.tif", "s_z1_t_z6.tif", "s_z2_t_z6.tif"],
+    "underscores": ["_a__z1.tif", "_a__z2.tif", "b_z1_.tif", "b_z2_.tif"],
+    "duplicate_numbers": ["a_z1.tif", "a_Z1.tif"],
+    "mixed_token_counts": ["a_z1.tif", "a_z2_z3.tif"],
+    "no_z_token": ["a.tif", "b.tif"],
+}
+ZSTACK_ID_LISTS = [["exp/exp_a", "exp/exp_b"], ["a/b", "a_b"], ["_x_", "__x"], ["p__q", "p_q"], ["dir/name_1", "dir/name_2"],
+                   ["alpha/alpha", "beta/beta"], ["s\\t", "u/v"]]
+
+
+def gen_zstacks():
+    import json
+    import shutil
+    from fl_tissue_model_tools import zstacks as zs
+    out = {"layouts": {}, "clean_ids": [], "proj": {}}
+    for name, files in ZSTACK_LAYOUTS.items():
+        root = Path(tempfile.mkdtemp(prefix="tmat_zs_"))
+        for f in files:
+            (root / f).parent.mkdir(parents=True, exist_ok=True)
+            (root / f).write_bytes(b"x")
+        rec = {"files": files}
+        try:
+            got = zs.find_zstack_image_sequences(str(root))
+            rec["sequences"] = {k: [os.path.relpath(p, root).replace(os.sep, "/") for p in v] for k, v in got.items()}
+        except Exception as e:                      # ZStackInputException and whatever else the reference raises
+            rec["error"] = type(e).__name__
+        if all("/" not in f for f in files):
+            rec["files_as_stacks"] = {k: os.path.relpath(v, root) for k, v in zs.find_zstack_files(str(root)).items()}
+        out["layouts"][name] = rec
+        shutil.rmtree(root)
+    for ids in ZSTACK_ID_LISTS:
+        out["clean_ids"].append({"in": ids, "out": zs.clean_zstack_ids(list(ids))})
+    rs = np.random.RandomState(5)
+    for Z in (1, 2, 5, 6):
+        st = rs.randint(0, 65536, (Z, 4, 5)).astype(np.uint16)
+        rec = {"stack": st.tolist()}
+        for m in ("min", "max", "avg", "med"):
+            r = getattr(zs, "proj_" + m)(st)
+            rec[m] = {"dtype": str(r.dtype), "values": r.tolist()}
+        out["proj"][str(Z)] = rec
+    (GOLD / "zstacks.json").write_text(json.dumps(out, indent=1))
+    print("zstacks.json", {k: len(v) for k, v in out.items()})
+
+
+
 if __name__ == "__main__":
     GOLD.mkdir(parents=True, exist_ok=True)
     _shims()
