@@ -214,10 +214,9 @@ static void prof_end(Ctx *c, hipStream_t st)
 
 static bool conv(Ctx *c, ConvArgs a, hipStream_t st)
 {
-    a.zeros = c->zero_row;
     bool dom = a.ksize == 3 && a.Cout % 128 == 0 && !a.relu_in;     // the conv_mfma_kernel<128,128,4,2,3,false> instantiation
     if (dom) {
-        double H = (double)(a.h << a.up), W = (double)(a.w << a.up);
+        double H = (double)a.h, W = (double)a.w;
         prof_begin(c, 2.0 * a.N * H * W * 9.0 * a.Cin * a.Cout, st);
     }
     bool ok = launch_conv(a, st);
@@ -239,7 +238,7 @@ int unet_down_dev(Ctx *c, const float *X, int n, float *dout, hipStream_t s)
         // prev = b0 (n, H, H, cin)
         launch_dwconv(b0, n, H, H, d.cin, 1, d.dw[0], b1, s);
         ConvArgs a{};
-        a.in = b1; a.N = n; a.h = H; a.w = H; a.Cin = d.cin; a.up = 0; a.relu_in = 0; a.ksize = 1; a.stride = 1;
+        a.in = b1; a.N = n; a.h = H; a.w = H; a.Cin = d.cin; a.relu_in = 0; a.ksize = 1; a.stride = 1;
         a.W = d.pw[0]; a.Cout = d.cout; a.scale = d.scale[0]; a.shift = d.shift[0]; a.resid = nullptr; a.rs = 0;
         a.relu_out = 1; a.out = b2;
         if (!conv(c, a, s)) return TMAT_E_ARG;
@@ -269,9 +268,9 @@ int unet_up_dev(Ctx *c, const float *dout, int n, float *Y, hipStream_t s)
     for (auto &u : c->up) {
         float *so = c->ubuf[so_idx];
         ConvArgs a{};
-        a.in = S; a.N = n; a.h = Hs; a.w = Hs; a.Cin = u.cin; a.up = up; a.relu_in = 1; a.ksize = 3; a.stride = 1;
+        a.in = S; a.N = n; a.h = Hs; a.w = Hs; a.Cin = u.cin; a.relu_in = 1; a.ksize = 3; a.stride = 1;
         a.W = u.ct[0];
-        if (up) { a.up = 0; a.ksize = 2; a.W = u.ct_sub; }      // 4 taps per output parity class instead of 9
+        if (up) { a.ksize = 2; a.W = u.ct_sub; }      // 4 taps per output parity class instead of 9
         a.Cout = u.cout; a.scale = u.scale[0]; a.shift = u.shift[0]; a.relu_out = 1; a.out = t1;
         if (!conv(c, a, s)) return TMAT_E_ARG;
         ConvArgs r{};
@@ -280,7 +279,7 @@ int unet_up_dev(Ctx *c, const float *dout, int n, float *Y, hipStream_t s)
         if (!conv(c, r, s)) return TMAT_E_ARG;
         const int Hl = Hs << up;
         ConvArgs b{};
-        b.in = t1; b.N = n; b.h = Hl; b.w = Hl; b.Cin = u.cout; b.up = 0; b.relu_in = 0; b.ksize = 3; b.stride = 1;
+        b.in = t1; b.N = n; b.h = Hl; b.w = Hl; b.Cin = u.cout; b.relu_in = 0; b.ksize = 3; b.stride = 1;
         b.W = u.ct[1]; b.Cout = u.cout; b.scale = u.scale[1]; b.shift = u.shift[1]; b.resid = rr; b.rs = up; b.relu_out = 0;
         b.out = so;
         if (!conv(c, b, s)) return TMAT_E_ARG;
@@ -370,10 +369,6 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
     c->patch = patch;
     c->max_patches = max_patches > 0 ? max_patches : 400;
     if (!hip_ok(hipStreamCreate(&c->stream), "hipStreamCreate") || !build_model(c, m)) { tmat_destroy((tmat_handle)c); return TMAT_E_WEIGHTS; }
-    {   // 2048 zero floats: the row out-of-image convolution taps read
-        std::vector<float> z(2048, 0.f);
-        if (!upload(c, z, &c->zero_row)) { tmat_destroy((tmat_handle)c); return TMAT_E_HIP; }
-    }
     // activation workspace: per patch (P/2)^2 * f0 floats for buf0/buf1 and twice that for buf2/buf3
     const size_t unit = (size_t)(patch / 2) * (patch / 2) * c->f0;
     const size_t sizes[4] = {unit, unit, 2 * unit, 2 * unit};

@@ -58,7 +58,6 @@ struct Ctx {
     std::vector<DownBlock> down;
     std::vector<UpBlock> up;
     float *final_w = nullptr;
-    float *zero_row = nullptr;
     float final_b = 0.f;
     std::vector<void *> owned;              // weight allocations
     float *buf[4] = {nullptr, nullptr, nullptr, nullptr};    // down-path ping-pong activations

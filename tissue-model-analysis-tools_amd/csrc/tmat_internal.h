@@ -15,7 +15,6 @@ bool hip_ok(hipError_t e, const char *what);
 struct ConvArgs {
     const float *in;      // stored tensor (N, h, w, Cin)
     int N, h, w, Cin;
-    int up;               // must be 0 (upsampled inputs go through the sub-pixel form, ksize 2)
     int relu_in;          // relu applied on load
     int ksize;            // 1 or 3; 2 = sub-pixel form of a 3x3 over the 2x nearest-upsampled stored tensor (out is 2h x 2w)
     int stride;           // 1, or 2 with ksize 1 (TF SAME 1x1 s2 samples even indices)
@@ -26,8 +25,7 @@ struct ConvArgs {
     const float *resid;   // nullable: v += resid[n][y >> rs][x >> rs][co]
     int rs;
     int relu_out;
-    float *out;           // (N, H/stride, W/stride, Cout), H = h << up
-    const float *zeros;   // >= Cin zero floats: source of out-of-image taps (set by tmat_api.cpp:conv)
+    float *out;           // (N, h/stride, w/stride, Cout); ksize 2: (N, 2h, 2w, Cout)
 };
 // returns false (and sets the error) on unsupported shapes
 bool launch_conv(const ConvArgs &a, hipStream_t s);

@@ -370,14 +370,13 @@ bool launch_conv(const ConvArgs &a, hipStream_t s)
     const int Ho = a.h / a.stride, Wo = a.w / a.stride;
     const long long Mll = (long long)a.N * Ho * Wo;
     if (!((a.ksize == 3 && a.stride == 1) || (a.ksize == 2 && a.stride == 1 && !a.resid) ||
-          (a.ksize == 1 && (a.stride == 1 || a.stride == 2))) || a.up != 0 || a.Cin % 32 || a.Cout % 64 ||
+          (a.ksize == 1 && (a.stride == 1 || a.stride == 2))) || a.Cin % 32 || a.Cout % 64 ||
         ((a.ksize * a.ksize * (a.Cin / 32)) & 1) || Mll <= 0 ||
         Mll > 0x7fffffffLL / 2 || (a.resid && a.rs && ((Ho | Wo) & 1))) {
         set_error("launch_conv: unsupported shape");
         return false;
     }
     const int M = (int)Mll;
-    if (!a.zeros || a.Cin > 2048) { set_error("launch_conv: missing zero row or Cin > 2048"); return false; }
     if (a.Cout % 128 == 0)
         launch_conv_cfg<TMAT_BM, 128, TMAT_WM, TMAT_WN>(a, M, Ho, Wo, s);
     else
