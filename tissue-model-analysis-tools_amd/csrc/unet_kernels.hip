@@ -37,7 +37,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 template <int BM, int BN, int WM, int WN, int KS, bool RELU>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 > 65536 ? 2 : WM * WN == 8 ? 4 : 2)) void conv_mfma_kernel(ConvArgs a, int M, int Ho, int Wo, int nMt, int nNt)
+#ifndef TMAT_CONV_WPS
+#define TMAT_CONV_WPS 4     // waves per SIMD the 8-wave conv kernel is compiled for (VGPR budget 512 / this)
+#endif
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 > 65536 ? 2 : WM * WN == 8 ? TMAT_CONV_WPS : 2)) void conv_mfma_kernel(ConvArgs a, int M, int Ho, int Wo, int nMt, int nNt)
 {
     // KS (1, 2 or 3) is a template parameter so that the 3x3 and the pointwise instantiations are distinct kernels
     // (distinct names in rocprofv3 traces: the 3x3 <128,128,2,2,3,*> instantiations are the dominant kernel).
@@ -203,7 +206,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
 #ifdef TMAT_ABL_NOBAR
 #define TMAT_LOOP_SYNC()
 #else
-#define TMAT_LOOP_SYNC() __syncthreads();
+// every wave retires its own DMA (explicitly: the ordering of LDS-DMA data for the readers is this wait followed by the
+// barrier, and must not depend on what hipcc chooses to put in front of a barrier), then the workgroup barrier
+#define TMAT_LOOP_SYNC() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
 #endif
 #define TMAT_READ_FRAGS(stage_)                                                        \
         _Pragma("unroll") for (int g = 0; g < 4; g++) {                                \
@@ -253,7 +258,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
 #endif
 
     TMAT_ISSUE_CHUNK(stage0)
-    __syncthreads();                // retires the DMA (hipcc emits vmcnt(0) in front of the barrier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
     // even chunks live in stage0, odd ones in stage1 (nchunks is even: host check)
     for (int c = 0; c < nchunks; c += 2) {
@@ -389,7 +395,10 @@ bool launch_conv(const ConvArgs &a, hipStream_t s)
 // (ky, kx) order, zero padding, optional ReLU on load.
 // ---------------------------------------------------------------------------------------------
 constexpr int DW_ROWS = 8;      // output rows per thread (a 3-row window slides down the column strip)
-__global__ __launch_bounds__(256) void dwconv_kernel(const float *__restrict__ in, int H, int W, int C, int c4shift,
+#ifndef TMAT_DW_WPS
+#define TMAT_DW_WPS 1
+#endif
+__global__ __launch_bounds__(256, TMAT_DW_WPS) void dwconv_kernel(const float *__restrict__ in, int H, int W, int C, int c4shift,
                                                      int relu_in, const float *__restrict__ Wd, float *__restrict__ out)
 {
     // grid: (ceil((H/8) * (W/4) * C4 / 256), N).  One thread = a strip of 4 consecutive pixels x 8 rows x 4 channels.
