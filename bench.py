@@ -159,6 +159,12 @@ def main():
     log(f"timed region {elapsed:.2f} s")
     conv_ms, conv_launches, conv_flops = handle.prof_read(True)
     handle.prof_enable(False)
+    # copies of the same synthetic image sit in different passes / positions of the batch: their rows must be identical
+    # (a cheap whole-run determinism / race screen of the timed output itself)
+    nd = len(distinct)
+    for i, r in enumerate(rows):
+        if r[1:] != rows[i % nd][1:]:
+            raise SystemExit(f"bench: image {i} and its copy {i % nd} produced different rows: {r} vs {rows[i % nd]}")
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -191,7 +197,7 @@ def main():
             "config": {"workload": f"{n_img} synthetic 1024x1024 uint16 Z-projections per GPU ({len(distinct)} distinct, tiled), "
                                    "tiled UNet seg (200 patches/image, random-init structured weights) + DMT branch extraction, "
                                    "default_branching_computation.json", "images_per_gpu": n_img, "patches_per_image": 200,
-                       "rows_gathered": n_rows, "host_threads": int(os.environ["TMAT_HOST_THREADS"])},
+                       "rows_gathered": n_rows, "copies_identical": True, "host_threads": int(os.environ["TMAT_HOST_THREADS"])},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                          "kernel": "tmat::conv_mfma_kernel<128, 128, 4, 2, 3, false> (3x3 implicit-GEMM on v_mfma_f32_32x32x2_f32; "

@@ -53,3 +53,25 @@ def test_predict_smooth_bitexact(handle, weights):
     assert got.dtype == np.float64 and got.shape == ref.shape
     nbad = int((got.view(np.uint64) != ref.view(np.uint64)).sum())
     assert nbad == 0, f"{nbad} of {got.size} differ, max |d| = {np.abs(got - ref).max()}"
+
+
+def test_large_launch_race_screen(weights):
+    """A launch that fills the chip several times over (1024 patches: 5000 workgroups per conv launch and more), made of
+    copies of 4 patches laid out so that copies land in different tiles / workgroups / XCDs.  Every copy must equal
+    the oracle bit for bit, three times in a row: an LDS-DMA ordering bug shows up as rare wrong tiles, not as a crash."""
+    from oracle import unet as ou
+    from tmat_amd import synth, _lib
+    rs = np.random.RandomState(9)
+    base = rs.uniform(0, 1, (4, 320, 320)).astype(np.float32)
+    ref = ou.forward_exact(weights, base)
+    n = 1024
+    idx = (np.arange(n) * 7 + (np.arange(n) // 13)) % 4
+    x = base[idx]
+    h = _lib.Handle(synth.pack_weights(weights), 0, n)
+    try:
+        for rep in range(3):
+            got = h.unet_predict(x)
+            bad = np.flatnonzero((got.view(np.uint32) != ref[idx].view(np.uint32)).reshape(n, -1).any(axis=1))
+            assert bad.size == 0, f"rep {rep}: {bad.size} of {n} patches differ (first {bad[:8]})"
+    finally:
+        h.close()
