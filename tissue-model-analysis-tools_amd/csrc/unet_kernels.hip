@@ -193,6 +193,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
     // sched_barrier(0) pins that order: left alone, hipcc sinks the reads next to their MFMAs and hoists the barrier.
     // (TMAT_ABL_* / TMAT_VAR_*: timing experiments of tools/gpu_variants.sh; ablations produce wrong results and nothing
     // of this is defined in the shipped build.)
+#if defined(TMAT_VAR_SETPRIO)
+#define TMAT_PRIO(x) __builtin_amdgcn_s_setprio(x);
+#else
+#define TMAT_PRIO(x)
+#endif
 #if defined(TMAT_VAR_NOPIN)
 #define TMAT_PIN()
 #else
@@ -251,7 +256,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
         TMAT_PIN()                                                                     \
         if (more) TMAT_LOOP_ISSUE(nxt)                                                 \
         TMAT_PIN()                                                                     \
+        TMAT_PRIO(1)                                                                   \
         TMAT_MFMAS()                                                                   \
+        TMAT_PRIO(0)                                                                   \
         TMAT_PIN()                                                                     \
         TMAT_LOOP_SYNC()                                                               \
     }
@@ -270,6 +277,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
 #undef TMAT_READ_FRAGS
 #undef TMAT_MFMAS
 #undef TMAT_PIN
+#undef TMAT_PRIO
 #undef TMAT_LOOP_ISSUE
 #undef TMAT_LOOP_SYNC
 #undef TMAT_RELU
