@@ -89,6 +89,14 @@ int tmat_postprocess_batch(tmat_handle h, const double *pred, int n, int hh, int
 int tmat_filter_edt_batch(tmat_handle h, const double *pred, int n, int hh, int ww, uint8_t *filtered, double *dist);
 
 /*
+ * transforms.filter_branch_seg_mask(mask, footprint, remove_isolated) (transforms.py:306-361) on the GPU for a batch of
+ * uint8 masks: use_median 1 = footprint disk(2) (the default), 0 = footprint None (compute_branches.py:293).
+ * mask, filtered (n, h, w) u8.  A handle from tmat_create_plain is enough.
+ */
+int tmat_filter_mask_batch(tmat_handle h, const uint8_t *mask, int n, int hh, int ww, int use_median, int remove_isolated,
+                           uint8_t *filtered);
+
+/*
  * The GPU stages after the medial-axis thinning (csrc/finish_kernels.hip): centerline_dt = EDT(~skel),
  * pred *= dist / (dist + centerline_dt) (compute_branches.py:341-344), skimage resize to (out_h, out_w)
  * (order 1, anti-aliased, :351-357) -> field f32, and rescale_intensity(field, (0, 255)) (:419) -> field255 f32.

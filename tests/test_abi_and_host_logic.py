@@ -81,6 +81,10 @@ def test_mirror_modules_validate_arguments():
     m = np.zeros((8, 8), bool)
     with pytest.raises(NotImplementedError):
         transforms.filter_branch_seg_mask(m, footprint=np.ones((3, 3)))
-    assert not transforms.filter_branch_seg_mask(m).any()
+    # the mirror runs on the GPU (tmat_filter_mask_batch); without a device it must fail loudly, not fall back
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            transforms.filter_branch_seg_mask(m)
     with pytest.raises(TypeError):
         stp.predict_img_with_smooth_windowing(np.zeros((10, 10), np.float32), 320, 2, lambda b, verbose=0: b)

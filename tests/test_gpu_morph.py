@@ -69,3 +69,23 @@ def test_finish_stage_matches_oracle(handle, shape, out):
         assert np.array_equal(field[i].view(np.uint32), want.view(np.uint32)), i
         w255 = morph.rescale_intensity(want, (0, 255)).astype(np.float32)
         assert np.array_equal(f255[i].view(np.uint32), np.ascontiguousarray(w255).view(np.uint32)), i
+
+
+@pytest.mark.parametrize("use_median,remove_isolated", [(True, True), (False, True), (True, False), (False, False)])
+def test_filter_branch_seg_mask_mirror_options(use_median, remove_isolated):
+    """tmat_amd.transforms.filter_branch_seg_mask (the reference seam transforms.py:306) runs on the GPU for every
+    combination of its options (compute_branches.py:293 uses footprint=None, remove_isolated=False), single mask and batch"""
+    import sys
+    from pathlib import Path as P
+    sys.path.insert(0, str(P(__file__).resolve().parents[1] / "tissue-model-analysis-tools_amd"))
+    from oracle import morph
+    from tmat_amd import transforms
+    rs = np.random.RandomState(11)
+    masks = [ndi.gaussian_filter(rs.normal(size=(90, 120)), s) > t for s, t in ((3, 0.02), (1.2, 0.05), (5, -0.01))]
+    masks += [unpack("d5", "mask")[:90, :120], np.zeros((90, 120), bool)]
+    fp = transforms.disk(2) if use_median else None
+    got = transforms.filter_branch_seg_mask(np.stack(masks), fp, remove_isolated)
+    for i, m in enumerate(masks):
+        want = morph.filter_branch_seg_mask(m, use_median, remove_isolated)
+        assert np.array_equal(got[i], want), i
+    assert np.array_equal(transforms.filter_branch_seg_mask(masks[0], fp, remove_isolated), got[0])

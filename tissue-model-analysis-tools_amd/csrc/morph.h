@@ -10,6 +10,8 @@ const int *morph_done_flags(void *workspace, int k, int H, int W);
 // pred (k, H, W) f64 device -> filtered mask (k, H, W) u8 device, EDT of it (k, H, W) f64 device; all async on `s`
 int filter_edt_dev(const double *pred, int k, int H, int W, int remove_isolated, void *workspace, uint8_t *filt_out,
                    double *dist_out, hipStream_t s);
+int filter_mask_dev(const double *pred, const uint8_t *mask_in, int k, int H, int W, int use_median, int remove_isolated,
+                    void *workspace, uint8_t *filt_out, double *dist_out, hipStream_t s);
 void launch_edt(const uint8_t *mask, int k, int H, int W, int *g, int *st, int *any_zero, double *dist, hipStream_t s);
 // finish_kernels.hip: EDT(~skel), centre-line weighting, anti-aliased resize, rescale to 0..255
 size_t finish_workspace_bytes(int k, int H, int W, int oh, int ow);

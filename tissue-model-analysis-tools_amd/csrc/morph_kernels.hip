@@ -29,6 +29,12 @@ static bool upload_lut()
 
 #define IMG_LOOP(p, n_px) for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < (n_px); p += gridDim.x * blockDim.x)
 
+__global__ void binarize_kernel(const uint8_t *__restrict__ m, uint8_t *__restrict__ seg, int npx)
+{
+    const size_t base = (size_t)blockIdx.y * npx;
+    IMG_LOOP(p, npx) seg[base + p] = m[base + p] != 0;
+}
+
 __global__ void threshold_kernel(const double *__restrict__ pred, uint8_t *__restrict__ seg, int npx)
 {
     const size_t base = (size_t)blockIdx.y * npx;
@@ -335,6 +341,14 @@ const int *morph_done_flags(void *workspace, int k, int H, int W)
 int filter_edt_dev(const double *pred, int k, int H, int W, int remove_isolated, void *workspace, uint8_t *filt_out,
                    double *dist_out, hipStream_t s)
 {
+    return filter_mask_dev(pred, nullptr, k, H, W, 1, remove_isolated, workspace, filt_out, dist_out, s);
+}
+
+// General form: the mask comes from `pred > 0.5` or, when `mask_in` is given, from a u8 mask; the 13-tap median is
+// optional (filter_branch_seg_mask(mask, footprint=None)); dist_out may be null (no EDT).
+int filter_mask_dev(const double *pred, const uint8_t *mask_in, int k, int H, int W, int use_median, int remove_isolated, void *workspace,
+                    uint8_t *filt_out, double *dist_out, hipStream_t s)
+{
     if (!upload_lut()) { set_error("morph: cannot upload the skeletonize table"); return -2; }
     const int npx = H * W;
     const size_t n = (size_t)k * npx;
@@ -345,8 +359,10 @@ int filter_edt_dev(const double *pred, int k, int H, int W, int remove_isolated,
     int *flags = st + 2 * n;            // [0,k): zhang changed, [k,2k): any_zero, [2k,3k): zhang done
     const dim3 grid((npx + 255) / 256 < 1024 ? (npx + 255) / 256 : 1024, k), blk(256);
 
-    hipLaunchKernelGGL(threshold_kernel, grid, blk, 0, s, pred, seg, npx);
-    hipLaunchKernelGGL(median13_kernel, grid, blk, 0, s, seg, med, H, W);
+    if (mask_in) hipLaunchKernelGGL(binarize_kernel, grid, blk, 0, s, mask_in, seg, npx);
+    else hipLaunchKernelGGL(threshold_kernel, grid, blk, 0, s, pred, seg, npx);
+    if (use_median) hipLaunchKernelGGL(median13_kernel, grid, blk, 0, s, seg, med, H, W);
+    else if (hipMemcpyAsync(med, seg, n, hipMemcpyDeviceToDevice, s) != hipSuccess) { set_error("morph: copy"); return -2; }
     // labels of the median-filtered mask
     hipLaunchKernelGGL(ccl_init_kernel, grid, blk, 0, s, med, ML, H, W);
     hipLaunchKernelGGL(ccl_merge_kernel, grid, blk, 0, s, med, ML, H, W);
@@ -380,7 +396,7 @@ int filter_edt_dev(const double *pred, int k, int H, int W, int remove_isolated,
     hipLaunchKernelGGL(decide_kernel, grid, blk, 0, s, SL, ML, fork, area, n1, n2, n3, npx, remove_isolated, drop);
     hipLaunchKernelGGL(apply_drop_kernel, grid, blk, 0, s, med, ML, drop, filt_out, npx);
     // exact EDT of the filtered mask
-    launch_edt(filt_out, k, H, W, g, st, flags + k, dist_out, s);
+    if (dist_out) launch_edt(filt_out, k, H, W, g, st, flags + k, dist_out, s);
     if (hipGetLastError() != hipSuccess) { set_error("morph: kernel launch failed"); return -2; }
     return 0;
 }

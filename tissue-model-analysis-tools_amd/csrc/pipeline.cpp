@@ -303,6 +303,28 @@ int tmat_filter_edt_batch(tmat_handle hd, const double *pred, int n, int hh, int
     return rc;
 }
 
+int tmat_filter_mask_batch(tmat_handle hd, const uint8_t *mask, int n, int hh, int ww, int use_median, int remove_isolated, uint8_t *filtered)
+{
+    Ctx *c = (Ctx *)hd;
+    if (!c || !mask || !filtered || n < 0 || hh < 1 || ww < 1) { set_error("tmat_filter_mask_batch: bad argument"); return TMAT_E_ARG; }
+    if (n == 0) return TMAT_OK;
+    TMAT_HIP(hipSetDevice(c->device));
+    const size_t npx = (size_t)n * hh * ww;
+    uint8_t *dm = nullptr, *df = nullptr; void *ws = nullptr;
+    int rc = TMAT_OK;
+    std::vector<int> conv(n, 0);
+    if (!hip_ok(hipMalloc((void **)&dm, npx), "hipMalloc") || !hip_ok(hipMalloc((void **)&df, npx), "hipMalloc") ||
+        !hip_ok(hipMalloc(&ws, morph_workspace_bytes(n, hh, ww)), "hipMalloc")) rc = TMAT_E_HIP;
+    if (!rc && !hip_ok(hipMemcpyAsync(dm, mask, npx, hipMemcpyHostToDevice, c->stream), "H2D")) rc = TMAT_E_HIP;
+    if (!rc && filter_mask_dev(nullptr, dm, n, hh, ww, use_median != 0, remove_isolated != 0, ws, df, nullptr, c->stream)) rc = TMAT_E_HIP;
+    if (!rc && (!hip_ok(hipMemcpyAsync(filtered, df, npx, hipMemcpyDeviceToHost, c->stream), "D2H") ||
+                !hip_ok(hipMemcpyAsync(conv.data(), morph_done_flags(ws, n, hh, ww), n * sizeof(int), hipMemcpyDeviceToHost, c->stream), "D2H") ||
+                !hip_ok(hipStreamSynchronize(c->stream), "sync"))) rc = TMAT_E_HIP;
+    for (int i = 0; i < n && !rc; i++) if (!conv[i]) { set_error("tmat_filter_mask_batch: thinning did not converge"); rc = TMAT_E_HIP; }
+    hipFree(dm); hipFree(df); hipFree(ws);
+    return rc;
+}
+
 int tmat_finish_batch(tmat_handle hd, const double *pred, const double *dist, const uint8_t *skel, int n, int hh, int ww, int out_h,
                       int out_w, float *field, float *field255)
 {

@@ -49,6 +49,7 @@ def lib():
     L.tmat_postprocess_batch.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.tmat_filter_edt_batch.argtypes = [vp, vp, i, i, i, vp, vp]
     L.tmat_finish_batch.argtypes = [vp, vp, vp, vp, i, i, i, i, i, vp, vp]
+    L.tmat_filter_mask_batch.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.tmat_zproj_batch.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.tmat_zproj_dev.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.tmat_dmt_graph.argtypes = [vp, vp, i, i, f, f, vp, i, vp, i, C.POINTER(i), C.POINTER(i)]
@@ -71,7 +72,7 @@ def lib():
 
 EXPORTS = [
     "tmat_last_error", "tmat_version", "tmat_create", "tmat_create_plain", "tmat_destroy", "tmat_sync", "tmat_unet_predict",
-    "tmat_predict_smooth", "tmat_segment_batch", "tmat_postprocess_batch", "tmat_filter_edt_batch", "tmat_finish_batch", "tmat_zproj_batch", "tmat_zproj_dev",
+    "tmat_predict_smooth", "tmat_segment_batch", "tmat_postprocess_batch", "tmat_filter_edt_batch", "tmat_finish_batch", "tmat_filter_mask_batch", "tmat_zproj_batch", "tmat_zproj_dev",
     "tmat_dmt_graph", "tmat_morse_stats",
     "tmat_analyze_batch_dev", "tmat_analyze_batch", "tmat_dev_alloc", "tmat_dev_free", "tmat_dev_upload",
     "tmat_prof_enable", "tmat_prof_read", "tmat_host_lanczos4_u16", "tmat_host_rescale01_u16",
@@ -156,6 +157,14 @@ class Handle:
         check(lib().tmat_finish_batch(self._h, ptr(pred), ptr(dist), ptr(skel), n, pred.shape[1], pred.shape[2], out_shape[0],
                                       out_shape[1], ptr(f), ptr(f255)), "tmat_finish_batch")
         return f, f255
+
+    def filter_mask(self, masks, use_median=True, remove_isolated=True):
+        """GPU filter_branch_seg_mask on (n, h, w) masks -> bool (n, h, w)"""
+        m = np.ascontiguousarray(np.asarray(masks) != 0, np.uint8)
+        out = np.empty_like(m)
+        check(lib().tmat_filter_mask_batch(self._h, ptr(m), m.shape[0], m.shape[1], m.shape[2], int(bool(use_median)),
+                                           int(bool(remove_isolated)), ptr(out)), "tmat_filter_mask_batch")
+        return out.astype(bool)
 
     ZPROJ_METHODS = {"fs": 0, "min": 1, "max": 2, "avg": 3, "med": 4}
 
