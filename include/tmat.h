@@ -76,7 +76,9 @@ int tmat_segment_batch(tmat_handle h, const uint16_t *imgs, int n, int H, int W,
  * (transforms.py:306-361) -> medial_axis + EDT centre-line weighting -> skimage resize to
  * img_dsamp_res = (out_h, out_w) (compute_branches.py:218-222: round(orig_shape * 384 / orig_width)),
  * order 1, anti-aliased -> f32.   pred: (n, h, w) f64; field: (n, out_h, out_w) f32.
- * Round 1: these stages execute on host worker threads; `h` may be NULL.
+ * Runs on the handle's device with the same split as the batch pipeline: GPU (threshold, filter, EDT) -> host
+ * (ordered medial-axis thinning, sequential by construction) -> GPU (EDT of the skeleton, weighting, resize).
+ * A handle from tmat_create_plain is enough.
  */
 int tmat_postprocess_batch(tmat_handle h, const double *pred, int n, int hh, int ww, int out_h, int out_w, float *field);
 

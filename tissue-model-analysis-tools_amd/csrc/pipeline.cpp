@@ -392,22 +392,46 @@ int tmat_zproj_batch(tmat_handle hd, const uint16_t *stacks, int n, int Z, int H
     return rc;
 }
 
-int tmat_postprocess_batch(tmat_handle, const double *pred, int n, int hh, int ww, int out_h, int out_w, float *field)
+// The post-processing of compute_branches.py:334-357 for a batch of probability maps, with the same split as the batch
+// pipeline: GPU (threshold, filter_branch_seg_mask, EDT) -> host (ordered medial-axis thinning, sequential by
+// construction) -> GPU (EDT of the skeleton, weighting, anti-aliased resize).  Chunked to bound device memory.
+int tmat_postprocess_batch(tmat_handle hd, const double *pred, int n, int hh, int ww, int out_h, int out_w, float *field)
 {
-    if (!pred || !field || n < 0 || hh < 1 || ww < 1 || out_h < 1 || out_w < 1) { set_error("tmat_postprocess_batch: bad argument"); return TMAT_E_ARG; }
-    std::atomic<int> next{0};
-    std::vector<std::thread> th;
-    const int nt = n_workers(n);
-    for (int t = 0; t < nt; t++)
-        th.emplace_back([&]() {
-            for (;;) {
-                const int i = next.fetch_add(1);
-                if (i >= n) break;
-                postprocess_image(pred + (size_t)i * hh * ww, hh, ww, out_h, out_w, field + (size_t)i * out_h * out_w);
-            }
-        });
-    for (auto &t : th) t.join();
-    return TMAT_OK;
+    Ctx *c = (Ctx *)hd;
+    if (!c || !pred || !field || n < 0 || hh < 1 || ww < 1 || out_h < 1 || out_w < 1) { set_error("tmat_postprocess_batch: bad argument"); return TMAT_E_ARG; }
+    if (n == 0) return TMAT_OK;
+    TMAT_HIP(hipSetDevice(c->device));
+    const size_t per = (size_t)hh * ww, oper = (size_t)out_h * out_w;
+    const int K = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)256 << 20) / (per * 8)));      // <= 256 MiB of f64 maps per chunk
+    double *dp = nullptr, *dd = nullptr; uint8_t *df = nullptr, *dsk = nullptr; void *ws = nullptr, *fws = nullptr; float *dfield = nullptr, *d255 = nullptr;
+    std::vector<uint8_t> filt((size_t)K * per), skel((size_t)K * per);
+    std::vector<double> dist((size_t)K * per);
+    std::vector<int> conv(K, 0);
+    int rc = TMAT_OK;
+    if (!hip_ok(hipMalloc((void **)&dp, K * per * 8), "hipMalloc") || !hip_ok(hipMalloc((void **)&dd, K * per * 8), "hipMalloc") ||
+        !hip_ok(hipMalloc((void **)&df, K * per), "hipMalloc") || !hip_ok(hipMalloc((void **)&dsk, K * per), "hipMalloc") ||
+        !hip_ok(hipMalloc(&ws, morph_workspace_bytes(K, hh, ww)), "hipMalloc") ||
+        !hip_ok(hipMalloc(&fws, finish_workspace_bytes(K, hh, ww, out_h, out_w)), "hipMalloc") ||
+        !hip_ok(hipMalloc((void **)&dfield, K * oper * 4), "hipMalloc") || !hip_ok(hipMalloc((void **)&d255, K * oper * 4), "hipMalloc")) rc = TMAT_E_HIP;
+    hipStream_t s = c->stream;
+    for (int i0 = 0; i0 < n && !rc; i0 += K) {
+        const int k = std::min(K, n - i0);
+        if (!hip_ok(hipMemcpyAsync(dp, pred + (size_t)i0 * per, k * per * 8, hipMemcpyHostToDevice, s), "H2D")) { rc = TMAT_E_HIP; break; }
+        if (filter_edt_dev(dp, k, hh, ww, 1, ws, df, dd, s)) { rc = TMAT_E_HIP; break; }
+        if (!hip_ok(hipMemcpyAsync(filt.data(), df, k * per, hipMemcpyDeviceToHost, s), "D2H") ||
+            !hip_ok(hipMemcpyAsync(dist.data(), dd, k * per * 8, hipMemcpyDeviceToHost, s), "D2H") ||
+            !hip_ok(hipMemcpyAsync(conv.data(), morph_done_flags(ws, k, hh, ww), k * sizeof(int), hipMemcpyDeviceToHost, s), "D2H") ||
+            !hip_ok(hipStreamSynchronize(s), "sync")) { rc = TMAT_E_HIP; break; }
+        for (int i = 0; i < k && !rc; i++) if (!conv[i]) { set_error("tmat_postprocess_batch: thinning did not converge"); rc = TMAT_E_HIP; }
+        if (rc) break;
+        parallel_images(k, [&](int i) { medial_axis_thin(filt.data() + i * per, dist.data() + i * per, hh, ww, skel.data() + i * per); });
+        if (!hip_ok(hipMemcpyAsync(dsk, skel.data(), k * per, hipMemcpyHostToDevice, s), "H2D")) { rc = TMAT_E_HIP; break; }
+        if (finish_dev(dp, dd, dsk, k, hh, ww, out_h, out_w, fws, dfield, d255, s)) { rc = TMAT_E_HIP; break; }
+        if (!hip_ok(hipMemcpyAsync(field + (size_t)i0 * oper, dfield, k * oper * 4, hipMemcpyDeviceToHost, s), "D2H") ||
+            !hip_ok(hipStreamSynchronize(s), "sync")) rc = TMAT_E_HIP;
+    }
+    hipFree(dp); hipFree(dd); hipFree(df); hipFree(dsk); hipFree(ws); hipFree(fws); hipFree(dfield); hipFree(d255);
+    return rc;
 }
 
 int tmat_analyze_batch_dev(tmat_handle hd, const uint16_t *imgs_dev, int n, int H, int W, double ds_ratio, int ds_width,
