@@ -181,6 +181,15 @@ int tmat_host_permutation(uint32_t seed, int n, uint32_t *out);
 int tmat_host_postprocess(const double *pred, int H, int W, int out_h, int out_w, float *field);
 
 /*
+ * The one collective of the path (compute_branches.py:585-594 writes its rows from one process; with one process per
+ * GPU the rows are gathered first): all-gather of result rows over RCCL.  `rccl_comm` is an ncclComm_t of the caller,
+ * `hip_stream` a hipStream_t (NULL = default stream); rows_dev (n_local) and out_dev (world * n_local) are device
+ * buffers; every rank passes the same n_local (pad short shards).  Asynchronous on the stream.  The Python host uses
+ * torch.distributed's all_gather instead, which is the same RCCL call on torch's communicator.
+ */
+int tmat_gather_rows(void *rccl_comm, const tmat_row *rows_dev, int n_local, tmat_row *out_dev, void *hip_stream);
+
+/*
  * Z projection of image stacks -- what scripts/compute_zproj.py:73-84 calls through proj_methods
  * (fl_tissue_model_tools/zstacks.py): "fs" proj_focus_stacking (zstacks.py:153-189: cv2.GaussianBlur 5x5 sigma 0, then
  * cv2.Laplacian(CV_64F, ksize 5), per pixel the value of the first slice with the strictly largest |Laplacian|),

@@ -50,6 +50,7 @@ def lib():
     L.tmat_filter_edt_batch.argtypes = [vp, vp, i, i, i, vp, vp]
     L.tmat_finish_batch.argtypes = [vp, vp, vp, vp, i, i, i, i, i, vp, vp]
     L.tmat_filter_mask_batch.argtypes = [vp, vp, i, i, i, i, i, vp]
+    L.tmat_gather_rows.argtypes = [vp, vp, i, vp, vp]
     L.tmat_zproj_batch.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.tmat_zproj_dev.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.tmat_dmt_graph.argtypes = [vp, vp, i, i, f, f, vp, i, vp, i, C.POINTER(i), C.POINTER(i)]
@@ -72,7 +73,7 @@ def lib():
 
 EXPORTS = [
     "tmat_last_error", "tmat_version", "tmat_create", "tmat_create_plain", "tmat_destroy", "tmat_sync", "tmat_unet_predict",
-    "tmat_predict_smooth", "tmat_segment_batch", "tmat_postprocess_batch", "tmat_filter_edt_batch", "tmat_finish_batch", "tmat_filter_mask_batch", "tmat_zproj_batch", "tmat_zproj_dev",
+    "tmat_predict_smooth", "tmat_segment_batch", "tmat_postprocess_batch", "tmat_filter_edt_batch", "tmat_finish_batch", "tmat_filter_mask_batch", "tmat_zproj_batch", "tmat_zproj_dev", "tmat_gather_rows",
     "tmat_dmt_graph", "tmat_morse_stats",
     "tmat_analyze_batch_dev", "tmat_analyze_batch", "tmat_dev_alloc", "tmat_dev_free", "tmat_dev_upload",
     "tmat_prof_enable", "tmat_prof_read", "tmat_host_lanczos4_u16", "tmat_host_rescale01_u16",

@@ -47,7 +47,7 @@ def build_hip(force=False, verbose=True) -> Path:
     with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if jobs or not OUT.exists():
-        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", str(OUT)] + [str(o) for o in objs] + ["-pthread"]
+        cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", str(OUT)] + [str(o) for o in objs] + ["-pthread", "-ldl"]
         run(cmd)
     return OUT
 

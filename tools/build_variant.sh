@@ -7,6 +7,6 @@ C=$ROOT/tissue-model-analysis-tools_amd/csrc
 mkdir -p $ROOT/build_variants
 /opt/rocm/bin/hipcc -x hip -c $C/unet_kernels.hip -o $ROOT/build_variants/unet_$1.o --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math $2
 OBJS=$(ls $C/build/*.o | grep -v unet_kernels)
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $ROOT/build_variants/libtmat_$1.so $OBJS $ROOT/build_variants/unet_$1.o -pthread
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $ROOT/build_variants/libtmat_$1.so $OBJS $ROOT/build_variants/unet_$1.o -pthread -ldl
 rm -f $ROOT/build_variants/unet_$1.o
 echo built $ROOT/build_variants/libtmat_$1.so
