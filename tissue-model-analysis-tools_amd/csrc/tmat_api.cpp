@@ -7,15 +7,23 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 
 namespace tmat {
 
-static thread_local std::string g_err;
-void set_error(const std::string &msg) { g_err = msg; }
+// One process-wide message (the last error of any thread): entry points run stages on worker threads, and a message
+// recorded there must reach the thread that called the entry point.
+static std::mutex g_err_mu;
+static std::string g_err;
+void set_error(const std::string &msg)
+{
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    g_err = msg;
+}
 bool hip_ok(hipError_t e, const char *what)
 {
     if (e == hipSuccess) return true;
-    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
     return false;
 }
 
@@ -327,7 +335,13 @@ using namespace tmat;
 
 extern "C" {
 
-const char *tmat_last_error(void) { return g_err.c_str(); }
+const char *tmat_last_error(void)
+{
+    static thread_local std::string copy;       // stays valid for the caller until its next call on this thread
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    copy = g_err;
+    return copy.c_str();
+}
 int tmat_version(void) { return 0x000100; }
 
 // A handle without a model: device + stream only, for the entry points that need no weights (tmat_zproj_*,
