@@ -119,3 +119,22 @@ def test_gather_rows_over_rccl_single_rank(handle):
     rccl.ncclCommDestroy(comm)
     _lib.check(L.tmat_dev_free(handle.raw, din), "free")
     _lib.check(L.tmat_dev_free(handle.raw, dout), "free")
+
+
+def test_rows_within_north_star_tolerance_of_the_as_written_network(handle, weights, images):
+    """The north-star bar against the reference CPU path: integer branch counts equal, branch lengths within 1e-4
+    relative.  The closest thing to that path available here is the oracle with the as-written network (PyTorch-CPU
+    convolutions in library order: 9-tap convolutions over the upsampled tensors, residual 1x1 after the upsampling);
+    the GPU path (sub-pixel form, hoisted residual, fixed FMA order) must agree with it to that bar, and its
+    probability map must stay within 2e-5 of it."""
+    from oracle import pipeline
+    from tmat_amd import _lib, branches
+    rows = branches.analyze_batch(handle, images, CFG, 500.0)
+    pred = np.empty((len(images), 320, 320), np.float64)
+    _lib.check(_lib.lib().tmat_segment_batch(handle.raw, _lib.ptr(np.ascontiguousarray(images)), len(images), 512, 512, 0.625,
+                                             _lib.ptr(pred)), "segment")
+    for i, img in enumerate(images):
+        (n0, tot0, avg0), inter = pipeline.analyze_image(img, weights, CFG, 500.0, unet_kind="torch", return_intermediates=True)
+        assert np.abs(pred[i] - inter["pred"]).max() < 2e-5
+        assert rows[i][1] == n0
+        assert rows[i][2] == pytest.approx(tot0, rel=1e-4) and rows[i][3] == pytest.approx(avg0, rel=1e-4)
