@@ -39,7 +39,9 @@ int tmat_version(void);
  * UNet-Xception of models.py:85-171 and loads its weights once per run (compute_branches.py:576).
  * `weights_blob` is the "TMATW001" container (tmat_amd/synth.py:pack_weights; Keras tensor
  * layouts) -- the offline stand-in for checkpoint_1.h5.
- * `max_patches` bounds the UNet batch held in HBM at once (0 = default 400 = two 1024^2 images).
+ * `max_patches` sizes the activation workspace, i.e. the UNet batch held in HBM at once (39 MB per patch; 0 = default
+ * 400 = two 1024^2 images per pass).  It is not a limit on the image size: an image that needs more patches runs its
+ * patch list in chunks, one image per pass.
  */
 int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max_patches, tmat_handle *out);
 /* A handle without weights (device + stream only) for the entry points that need no model: tmat_zproj_*,

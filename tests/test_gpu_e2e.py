@@ -138,3 +138,28 @@ def test_rows_within_north_star_tolerance_of_the_as_written_network(handle, weig
         assert np.abs(pred[i] - inter["pred"]).max() < 2e-5
         assert rows[i][1] == n0
         assert rows[i][2] == pytest.approx(tot0, rel=1e-4) and rows[i][3] == pytest.approx(avg0, rel=1e-4)
+
+
+def test_images_that_need_more_patches_than_the_workspace(weights, images, oracle_runs):
+    """max_patches only sizes the activation workspace: an image that needs more patches (72 here, workspace 40) runs
+    its patch list in chunks, one image per pass, with the same rows / probability maps as the oracle"""
+    from tmat_amd import _lib, branches, synth
+    h = _lib.Handle(synth.pack_weights(weights), 0, 40)
+    try:
+        rows = branches.analyze_batch(h, images, CFG, 500.0)
+        for i, r in enumerate(rows):
+            assert (r[1], r[2], r[3]) == tuple(oracle_runs[i][0]), i
+        pred = np.empty((len(images), 320, 320), np.float64)
+        _lib.check(_lib.lib().tmat_segment_batch(h.raw, _lib.ptr(np.ascontiguousarray(images)), len(images), 512, 512, 0.625,
+                                                 _lib.ptr(pred)), "segment")
+        for i in range(len(images)):
+            assert np.array_equal(pred[i].view(np.uint64), oracle_runs[i][1]["pred"].view(np.uint64))
+        # a second geometry on the same handle afterwards (buffers regrow / are reused)
+        small = synth.synth_image(4, 256, n_vessels=10, scale=1.0)
+        big = _lib.Handle(synth.pack_weights(weights), 0, 128)
+        try:
+            assert branches.analyze_batch(h, small[None], CFG, 250.0) == branches.analyze_batch(big, small[None], CFG, 250.0)
+        finally:
+            big.close()
+    finally:
+        h.close()

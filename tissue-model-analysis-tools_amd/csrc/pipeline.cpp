@@ -101,13 +101,17 @@ static int enqueue_front(Ctx *c, const uint16_t *imgs_dev, int k, int slot, cons
     // Default: both halves on the main stream.  TMAT_STREAMS=2 puts this half on the second stream; measured +1.8 %
     // images/s, but every kernel of the MFMA half then shares the CUs with a memory-bound one and its own duration
     // (the roofline measurement) stretches by 20 %, so the overlap is opt-in.
-    hipStream_t s = use_one_stream() ? c->stream : c->stream2;
+    // an image that needs more patches than the activation workspace holds: the whole network runs here, chunk by
+    // chunk, on the main stream (enqueue_back then only blends)
+    const bool oversize = g.tiles_per_img > c->max_patches;
+    hipStream_t s = (use_one_stream() || oversize) ? c->stream : c->stream2;
     launch_lanczos(imgs_dev, k, b.H, b.W, b.h, b.w, b.xi, b.xc, b.yi, b.yc, b.tmp, b.small, s);
     launch_rescale01(b.small, k, (size_t)b.h * b.w, b.mn, b.mx, b.x, s);
     float *mn = (float *)c->scratch, *mx = mn + k;
     launch_minmax_f32(b.x, k, (size_t)b.h * b.w, mn, mx, s);
     launch_extract_tiles(b.x, mn, k, g, c->patch_in, s);
-    int rc = unet_down_dev(c, c->patch_in, k * g.tiles_per_img, c->dout[slot], s);
+    int rc = oversize ? unet_forward_dev(c, c->patch_in, k * g.tiles_per_img, c->patch_out, s)
+                      : unet_down_dev(c, c->patch_in, k * g.tiles_per_img, c->dout[slot], s);
     if (rc) return rc;
     TMAT_HIP(hipEventRecord(c->ev_down[slot], s));
     return TMAT_OK;
@@ -117,7 +121,7 @@ static int enqueue_back(Ctx *c, int k, int slot, const TileGeom &g)
     PassBuf &b = c->pass;
     hipStream_t s = c->stream;
     TMAT_HIP(hipStreamWaitEvent(s, c->ev_down[slot], 0));
-    int rc = unet_up_dev(c, c->dout[slot], k * g.tiles_per_img, c->patch_out, s);
+    int rc = g.tiles_per_img > c->max_patches ? TMAT_OK : unet_up_dev(c, c->dout[slot], k * g.tiles_per_img, c->patch_out, s);
     if (rc) return rc;
     launch_blend(c->patch_out, c->win1d, k, g, b.pred[slot], s);
     // binary morphology on the GPU: threshold, median, labelling, perimeter, thinning, fork test, EDT (remove_isolated=True
@@ -211,8 +215,8 @@ static int analyze_dev(Ctx *c, const uint16_t *imgs_dev, int n, int H, int W, do
     gp.fh = round_half_even((double)H * ((double)ds_width / (double)W));
     gp.fw = round_half_even((double)W * ((double)ds_width / (double)W));
     TileGeom g = make_geom(h, w, c->patch);
-    if (g.tiles_per_img > c->max_patches) { set_error("analyze: image needs more patches than max_patches"); return TMAT_E_ARG; }
-    const int K = std::min(n, c->max_patches / g.tiles_per_img);
+    const int K = std::min(n, std::max(1, c->max_patches / g.tiles_per_img));      // one image per pass when it needs > max_patches
+    { int rc0 = ensure_patch_io(c, K * g.tiles_per_img); if (rc0) return rc0; }
     int rc = ensure_pass_buffers(c, K, H, W, h, w, gp.fh, gp.fw);
     if (rc) return rc;
     for (int i = 0; i < n; i++) { rows[i].index = first_index + i; rows[i].count = 0; rows[i].total_px = 0; rows[i].avg_px = 0; }
@@ -262,8 +266,7 @@ int tmat_segment_batch(tmat_handle hd, const uint16_t *imgs, int n, int H, int W
     const int h = round_half_even((double)H * ds_ratio), w = round_half_even((double)W * ds_ratio);
     if (h < 1 || w < 1) { set_error("tmat_segment_batch: target shape is empty"); return TMAT_E_ARG; }
     TileGeom g = make_geom(h, w, c->patch);
-    if (g.tiles_per_img > c->max_patches) { set_error("tmat_segment_batch: image needs more patches than max_patches"); return TMAT_E_ARG; }
-    const int K = std::min(n, c->max_patches / g.tiles_per_img);
+    const int K = std::min(n, std::max(1, c->max_patches / g.tiles_per_img));
     int rc = ensure_pass_buffers(c, K, H, W, h, w, std::max(1, c->pass.fh), std::max(1, c->pass.fw));
     if (rc) return rc;
     uint16_t *dimg = nullptr;

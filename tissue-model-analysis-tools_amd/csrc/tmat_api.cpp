@@ -299,11 +299,36 @@ int unet_up_dev(Ctx *c, const float *dout, int n, float *Y, hipStream_t s)
     return TMAT_OK;
 }
 
-int unet_forward_dev(Ctx *c, const float *X, int n, float *Y)
+// n may exceed max_patches (an image that needs more patches than the activation workspace holds): the patch list
+// is then walked in chunks of max_patches, all on stream `s`
+int unet_forward_dev(Ctx *c, const float *X, int n, float *Y, hipStream_t s)
 {
-    int rc = unet_down_dev(c, X, n, c->dout[0], c->stream);
-    if (rc) return rc;
-    return unet_up_dev(c, c->dout[0], n, Y, c->stream);
+    const size_t pp = (size_t)c->patch * c->patch;
+    for (int i0 = 0; i0 < n; i0 += c->max_patches) {
+        const int k = std::min(c->max_patches, n - i0);
+        int rc = unet_down_dev(c, X + (size_t)i0 * pp, k, c->dout[0], s);
+        if (rc) return rc;
+        rc = unet_up_dev(c, c->dout[0], k, Y + (size_t)i0 * pp, s);
+        if (rc) return rc;
+    }
+    return TMAT_OK;
+}
+
+// patch_in / patch_out hold max_patches patches; an image that needs more gets larger ones (2 x 0.41 MB per patch).
+// Only called between entry points (nothing in flight uses the old buffers).
+int ensure_patch_io(Ctx *c, int n_patches)
+{
+    if (n_patches <= c->patch_cap) return TMAT_OK;
+    TMAT_HIP(hipStreamSynchronize(c->stream));
+    if (c->patch_in) hipFree(c->patch_in);
+    if (c->patch_out) hipFree(c->patch_out);
+    c->patch_in = c->patch_out = nullptr;
+    c->patch_cap = 0;
+    const size_t bytes = (size_t)c->patch * c->patch * n_patches * sizeof(float);
+    TMAT_HIP(hipMalloc((void **)&c->patch_in, bytes));
+    TMAT_HIP(hipMalloc((void **)&c->patch_out, bytes));
+    c->patch_cap = n_patches;
+    return TMAT_OK;
 }
 
 // predict_img_with_smooth_windowing on device: x_dev (n, hh, ww) f32 -> pred_dev (n, hh, ww) f64
@@ -311,8 +336,8 @@ int predict_smooth_dev(Ctx *c, const float *x_dev, int n, int hh, int ww, double
 {
     const int P = c->patch;
     TileGeom g = make_geom(hh, ww, P);
-    if (g.tiles_per_img > c->max_patches) { set_error("predict_smooth: image needs more patches than max_patches"); return TMAT_E_ARG; }
-    const int per_pass = c->max_patches / g.tiles_per_img;
+    const int per_pass = std::max(1, c->max_patches / g.tiles_per_img);
+    { int rc = ensure_patch_io(c, per_pass * g.tiles_per_img); if (rc) return rc; }
     size_t need_pv = (size_t)std::min(n, per_pass) * 2 * sizeof(float);
     if (need_pv > c->scratch_bytes) { set_error("predict_smooth: scratch too small"); return TMAT_E_ARG; }
     float *mn = (float *)c->scratch, *mx = mn + std::min(n, per_pass);
@@ -321,7 +346,7 @@ int predict_smooth_dev(Ctx *c, const float *x_dev, int n, int hh, int ww, double
         const float *xi = x_dev + (size_t)i0 * hh * ww;
         launch_minmax_f32(xi, k, (size_t)hh * ww, mn, mx, c->stream);
         launch_extract_tiles(xi, mn, k, g, c->patch_in, c->stream);
-        int rc = unet_forward_dev(c, c->patch_in, k * g.tiles_per_img, c->patch_out);
+        int rc = unet_forward_dev(c, c->patch_in, k * g.tiles_per_img, c->patch_out, c->stream);
         if (rc) return rc;
         launch_blend(c->patch_out, c->win1d, k, g, pred_dev + (size_t)i0 * hh * ww, c->stream);
     }
@@ -412,6 +437,7 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
     if (!hip_ok(hipMalloc((void **)&c->patch_in, pp), "hipMalloc(patch_in)") ||
         !hip_ok(hipMalloc((void **)&c->patch_out, pp), "hipMalloc(patch_out)") ||
         !hip_ok(hipMalloc((void **)&c->scratch, c->scratch_bytes), "hipMalloc(scratch)")) { tmat_destroy((tmat_handle)c); return TMAT_E_HIP; }
+    c->patch_cap = c->max_patches;
     // squared-spline window (smooth_tiled_predictions.py:26-41), f64, on host then uploaded
     {
         const int ws = patch;
@@ -486,7 +512,7 @@ int tmat_unet_predict(tmat_handle h, const float *x, int n, float *y)
     for (int i0 = 0; i0 < n; i0 += c->max_patches) {
         int k = std::min(c->max_patches, n - i0);
         TMAT_HIP(hipMemcpyAsync(c->patch_in, x + i0 * per, k * per * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        int rc = unet_forward_dev(c, c->patch_in, k, c->patch_out);
+        int rc = unet_forward_dev(c, c->patch_in, k, c->patch_out, c->stream);
         if (rc) return rc;
         TMAT_HIP(hipMemcpyAsync(y + i0 * per, c->patch_out, k * per * sizeof(float), hipMemcpyDeviceToHost, c->stream));
         TMAT_HIP(hipStreamSynchronize(c->stream));

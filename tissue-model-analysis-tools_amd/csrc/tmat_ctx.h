@@ -67,6 +67,7 @@ struct Ctx {
     hipStream_t stream3 = nullptr;                           // third stream: finish stage of pass p-1 (after the host thinning)
     hipEvent_t ev_down[2] = {nullptr, nullptr};
     float *patch_in = nullptr, *patch_out = nullptr;
+    int patch_cap = 0;                                       // patches patch_in / patch_out hold (>= max_patches)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
     double *win1d = nullptr;
@@ -98,7 +99,8 @@ struct Ctx {
     int64_t prof_launches = 0;
 };
 
-int unet_forward_dev(Ctx *c, const float *X, int n, float *Y);
+int unet_forward_dev(Ctx *c, const float *X, int n, float *Y, hipStream_t s);
+int ensure_patch_io(Ctx *c, int n_patches);
 int unet_down_dev(Ctx *c, const float *X, int n, float *dout, hipStream_t s);
 int unet_up_dev(Ctx *c, const float *dout, int n, float *Y, hipStream_t s);
 int predict_smooth_dev(Ctx *c, const float *x_dev, int n, int hh, int ww, double *pred_dev);
