@@ -51,6 +51,11 @@ void tmat_destroy(tmat_handle h);
 /* blocks until all work queued on the handle's stream is done */
 int tmat_sync(tmat_handle h);
 
+/* Bit depth of the images the next segment / analyze calls receive (16, the default, or 8).  Images always cross the
+ * ABI as uint16; cv2.resize saturates its result to the depth of its input (compute_branches.py:309-312), so 8-bit
+ * sources (widened by the caller) must saturate the Lanczos overshoot at 255 instead of 65535. */
+int tmat_set_input_depth(tmat_handle h, int bits);
+
 /*
  * keras_model.predict on a patch batch (reference models.py:644 as called from
  * smooth_tiled_predictions.py:179,182): x (n, P, P) f32 -> y (n, P, P) f32 sigmoid output

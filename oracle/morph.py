@@ -62,9 +62,10 @@ def _axis_table(n_src: int, n_dst: int):
     return idx, co
 
 
-def lanczos4_resize_u16(img: np.ndarray, out_hw) -> np.ndarray:
+def lanczos4_resize_u16(img: np.ndarray, out_hw, sat: int = 65535) -> np.ndarray:
     """u16 (H, W) -> u16 (h, w): separable 8-tap Lanczos4, replicate border, f32 accumulate
-    left-to-right (no FMA), horizontal then vertical, round-half-even + saturate."""
+    left-to-right (no FMA), horizontal then vertical, round-half-even + saturate (to `sat`: cv2 saturates to the
+    depth of its input, so an image that was uint8 before widening uses 255)."""
     H, W = img.shape
     h, w = out_hw
     xi, xc = _axis_table(W, w)
@@ -76,7 +77,7 @@ def lanczos4_resize_u16(img: np.ndarray, out_hw) -> np.ndarray:
     out = np.zeros((h, w), np.float32)
     for k in range(8):
         out = (out + tmp[yi[:, k], :] * yc[:, k, None]).astype(np.float32)
-    return np.clip(np.rint(out), 0, 65535).astype(np.uint16)
+    return np.clip(np.rint(out), 0, sat).astype(np.uint16)
 
 
 def target_shape(shape, ratio: float):

@@ -27,18 +27,18 @@ def px_params(config: dict, field_width: int, image_width_microns: float):
     return sw_px, min_px, max_px
 
 
-def segment(img_u16: np.ndarray, weights, ds_ratio=0.625, unet_kind="exact", patch=320):
+def segment(img_u16: np.ndarray, weights, ds_ratio=0.625, unet_kind="exact", patch=320, input_bits=16):
     tgt = morph.target_shape(img_u16.shape, ds_ratio)
-    small = morph.lanczos4_resize_u16(img_u16, tgt)
+    small = morph.lanczos4_resize_u16(img_u16, tgt, sat=(1 << input_bits) - 1)
     x = morph.rescale_intensity(small, (0, 1)).astype(np.float32)
     pf = unet.predict_exact(weights) if unet_kind == "exact" else unet.predict_torch(weights)
     return blend.predict_img_with_smooth_windowing(x, patch, 2, pf)
 
 
 def analyze_image(img_u16: np.ndarray, weights, config: dict, image_width_microns: float, ds_ratio=0.625,
-                  unet_kind="exact", return_intermediates=False):
+                  unet_kind="exact", return_intermediates=False, input_bits=16):
     """-> (count, total_px, avg_px) for one image and one (thresh1, thresh2) pair."""
-    pred = segment(img_u16, weights, ds_ratio, unet_kind)
+    pred = segment(img_u16, weights, ds_ratio, unet_kind, input_bits=input_bits)
     out_shape = morph.dsamp_shape(img_u16.shape, DOWNSAMPLE_WIDTH)
     field, seg, skel = morph.postprocess(pred, out_shape)
     f255 = morph.rescale_intensity(field, (0, 255))

@@ -163,3 +163,21 @@ def test_images_that_need_more_patches_than_the_workspace(weights, images, oracl
             big.close()
     finally:
         h.close()
+
+
+def test_eight_bit_sources_saturate_at_255(handle, weights):
+    """cv2.resize saturates its result to the depth of its input: for an image that was uint8 the Lanczos overshoot next
+    to saturated regions clips at 255, not at 65535 (tmat_set_input_depth / input_bits=8)"""
+    from oracle import morph, pipeline
+    from tmat_amd import branches, synth
+    img16 = synth.synth_image(1, 512, n_vessels=12, scale=1.0)
+    img8 = np.clip(img16.astype(np.float64) / 120.0, 0, 255).astype(np.uint8)      # large saturated areas
+    assert (img8 == 255).mean() > 0.01
+    wide = img8.astype(np.uint16)
+    s8 = morph.lanczos4_resize_u16(wide, (320, 320), sat=255)
+    s16 = morph.lanczos4_resize_u16(wide, (320, 320))
+    assert s16.max() > 255 and s8.max() == 255                                   # the overshoot exists and is clipped
+    row8 = branches.analyze_batch(handle, wide[None], CFG, 500.0, input_bits=8)[0]
+    assert row8[1:] == tuple(pipeline.analyze_image(wide, weights, CFG, 500.0, input_bits=8))
+    row16 = branches.analyze_batch(handle, wide[None], CFG, 500.0)[0]             # and the default depth is restored per call
+    assert row16[1:] == tuple(pipeline.analyze_image(wide, weights, CFG, 500.0))

@@ -25,7 +25,7 @@
 namespace tmat {
 
 void launch_lanczos(const uint16_t *img, int n, int H, int W, int h, int w, const int *xi, const float *xc, const int *yi,
-                    const float *yc, float *tmp, uint16_t *out, hipStream_t s);
+                    const float *yc, float *tmp, uint16_t *out, float sat, hipStream_t s);
 void launch_rescale01(const uint16_t *x, int n, size_t per, int *mn, int *mx, float *out, hipStream_t s);
 
 static int round_half_even(double v) { return (int)std::nearbyint(v); }
@@ -78,7 +78,7 @@ static int ensure_pass_buffers(Ctx *c, int K, int H, int W, int h, int w, int fh
 static int enqueue_segment(Ctx *c, const uint16_t *imgs_dev, int k, int slot)
 {
     PassBuf &b = c->pass;
-    launch_lanczos(imgs_dev, k, b.H, b.W, b.h, b.w, b.xi, b.xc, b.yi, b.yc, b.tmp, b.small, c->stream);
+    launch_lanczos(imgs_dev, k, b.H, b.W, b.h, b.w, b.xi, b.xc, b.yi, b.yc, b.tmp, b.small, c->input_sat, c->stream);
     launch_rescale01(b.small, k, (size_t)b.h * b.w, b.mn, b.mx, b.x, c->stream);
     int rc = predict_smooth_dev(c, b.x, k, b.h, b.w, b.pred[slot]);
     if (rc) return rc;
@@ -105,7 +105,7 @@ static int enqueue_front(Ctx *c, const uint16_t *imgs_dev, int k, int slot, cons
     // chunk, on the main stream (enqueue_back then only blends)
     const bool oversize = g.tiles_per_img > c->max_patches;
     hipStream_t s = (use_one_stream() || oversize) ? c->stream : c->stream2;
-    launch_lanczos(imgs_dev, k, b.H, b.W, b.h, b.w, b.xi, b.xc, b.yi, b.yc, b.tmp, b.small, s);
+    launch_lanczos(imgs_dev, k, b.H, b.W, b.h, b.w, b.xi, b.xc, b.yi, b.yc, b.tmp, b.small, c->input_sat, s);
     launch_rescale01(b.small, k, (size_t)b.h * b.w, b.mn, b.mx, b.x, s);
     float *mn = (float *)c->scratch, *mx = mn + k;
     launch_minmax_f32(b.x, k, (size_t)b.h * b.w, mn, mx, s);

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void lanczos_h_kernel(const uint16_t *__restri
 
 __global__ __launch_bounds__(256) void lanczos_v_kernel(const float *__restrict__ tmp, int H, int h, int w,
                                                         const int *__restrict__ yi, const float *__restrict__ yc,
-                                                        uint16_t *__restrict__ out)
+                                                        uint16_t *__restrict__ out, float sat)
 {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void lanczos_v_kernel(const float *__restrict_
 #pragma unroll
     for (int k = 0; k < 8; k++) acc = acc + base[(size_t)yi[y * 8 + k] * w] * yc[y * 8 + k];
     float r = rintf(acc);
-    r = fminf(fmaxf(r, 0.0f), 65535.0f);
+    r = fminf(fmaxf(r, 0.0f), sat);          // saturate_cast to the source depth: 65535, or 255 for 8-bit sources
     out[((size_t)n * h + y) * w + x] = (uint16_t)r;
 }
 
@@ -70,10 +70,10 @@ __global__ __launch_bounds__(256) void rescale01_kernel(const uint16_t *__restri
 }
 
 void launch_lanczos(const uint16_t *img, int n, int H, int W, int h, int w, const int *xi, const float *xc, const int *yi,
-                    const float *yc, float *tmp, uint16_t *out, hipStream_t s)
+                    const float *yc, float *tmp, uint16_t *out, float sat, hipStream_t s)
 {
     hipLaunchKernelGGL(lanczos_h_kernel, dim3((w + 63) / 64, (H + 3) / 4, n), dim3(256), 0, s, img, H, W, w, xi, xc, tmp);
-    hipLaunchKernelGGL(lanczos_v_kernel, dim3((w + 63) / 64, (h + 3) / 4, n), dim3(256), 0, s, tmp, H, h, w, yi, yc, out);
+    hipLaunchKernelGGL(lanczos_v_kernel, dim3((w + 63) / 64, (h + 3) / 4, n), dim3(256), 0, s, tmp, H, h, w, yi, yc, out, sat);
 }
 
 void launch_rescale01(const uint16_t *x, int n, size_t per, int *mn, int *mx, float *out, hipStream_t s)

@@ -566,6 +566,14 @@ int tmat_dev_upload(tmat_handle h, void *dev_dst, const void *host_src, size_t b
     return TMAT_OK;
 }
 
+int tmat_set_input_depth(tmat_handle h, int bits)
+{
+    Ctx *c = (Ctx *)h;
+    if (!c || (bits != 8 && bits != 16)) { set_error("tmat_set_input_depth: bits must be 8 or 16"); return TMAT_E_ARG; }
+    c->input_sat = bits == 8 ? 255.f : 65535.f;
+    return TMAT_OK;
+}
+
 int tmat_prof_enable(tmat_handle h, int on)
 {
     Ctx *c = (Ctx *)h;

@@ -67,6 +67,7 @@ struct Ctx {
     hipStream_t stream3 = nullptr;                           // third stream: finish stage of pass p-1 (after the host thinning)
     hipEvent_t ev_down[2] = {nullptr, nullptr};
     float *patch_in = nullptr, *patch_out = nullptr;
+    float input_sat = 65535.f;                               // Lanczos saturation: 65535, or 255 for 8-bit sources (tmat_set_input_depth)
     int patch_cap = 0;                                       // patches patch_in / patch_out hold (>= max_patches)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;

@@ -84,11 +84,9 @@ def load_image_2d(path: str, channel=None, time=None) -> np.ndarray:
         a = a[..., channel] if a.shape[-1] <= 4 else a[channel]
     if a.ndim != 2:
         raise ValueError(f"{path}: expected a single-channel 2-D image, got shape {a.shape}")
-    if a.dtype == np.uint8:
-        a = a.astype(np.uint16)
-    if a.dtype != np.uint16:
+    if a.dtype not in (np.uint8, np.uint16):
         raise ValueError(f"{path}: expected uint8/uint16 pixels, got {a.dtype}")
-    return a
+    return a        # uint8 images are widened at the ABI and flagged (input_bits=8): cv2.resize saturates to the source depth
 
 
 def main(args=None):
@@ -162,12 +160,12 @@ def main(args=None):
                       "Exiting...", flush=True)
                 sys.exit(1)
             width_um = img.shape[-1] * px
-        groups.setdefault((img.shape, float(width_um)), []).append((ids.index(img_id), img))
-    for (shape, width_um), items in groups.items():
-        batch = np.stack([im for _, im in items])
+        groups.setdefault((img.shape, float(width_um), 8 * img.dtype.itemsize), []).append((ids.index(img_id), img))
+    for (shape, width_um, bits), items in groups.items():
+        batch = np.stack([im for _, im in items]).astype(np.uint16)
         for cfg, suffix in grid:
             rows = branches.analyze_batch(model.handle, batch, config, width_um, model.ds_ratio,
-                                          thresh=(cfg["thresh1"], cfg["thresh2"]))
+                                          thresh=(cfg["thresh1"], cfg["thresh2"]), input_bits=bits)
             um = lambda px: branches.pixels_to_microns(px, DOWNSAMPLE_WIDTH, width_um)
             for (gidx, _), r in zip(items, rows):
                 results[suffix].append((gidx, r[1], um(r[2]), um(r[3])))

@@ -43,6 +43,7 @@ def lib():
     L.tmat_destroy.argtypes = [vp]
     L.tmat_destroy.restype = None
     L.tmat_sync.argtypes = [vp]
+    L.tmat_set_input_depth.argtypes = [vp, i]
     L.tmat_unet_predict.argtypes = [vp, vp, i, vp]
     L.tmat_predict_smooth.argtypes = [vp, vp, i, i, i, vp]
     L.tmat_segment_batch.argtypes = [vp, vp, i, i, i, C.c_double, vp]
@@ -72,7 +73,7 @@ def lib():
 
 
 EXPORTS = [
-    "tmat_last_error", "tmat_version", "tmat_create", "tmat_create_plain", "tmat_destroy", "tmat_sync", "tmat_unet_predict",
+    "tmat_last_error", "tmat_version", "tmat_create", "tmat_create_plain", "tmat_destroy", "tmat_sync", "tmat_set_input_depth", "tmat_unet_predict",
     "tmat_predict_smooth", "tmat_segment_batch", "tmat_postprocess_batch", "tmat_filter_edt_batch", "tmat_finish_batch", "tmat_filter_mask_batch", "tmat_zproj_batch", "tmat_zproj_dev", "tmat_gather_rows",
     "tmat_dmt_graph", "tmat_morse_stats",
     "tmat_analyze_batch_dev", "tmat_analyze_batch", "tmat_dev_alloc", "tmat_dev_free", "tmat_dev_upload",

@@ -54,8 +54,9 @@ def threshold_grid(config: dict):
 
 
 def analyze_batch(handle: _lib.Handle, imgs: np.ndarray, config: dict, image_width_microns: float, ds_ratio: float = 0.625,
-                  thresh=(5.0, 10.0), first_index: int = 0, dev_ptr=None):
-    """imgs (n, H, W) uint16 (host) or a device pointer + shape -> list of (index, count, total_px, avg_px)."""
+                  thresh=(5.0, 10.0), first_index: int = 0, dev_ptr=None, input_bits: int = 16):
+    """imgs (n, H, W) uint16 (host) or a device pointer + shape -> list of (index, count, total_px, avg_px).
+    `input_bits` = 8 for images that were uint8 before widening (cv2.resize saturates to the source depth)."""
     if dev_ptr is None:
         imgs = np.ascontiguousarray(imgs, np.uint16)
         n, H, W = imgs.shape
@@ -64,6 +65,7 @@ def analyze_batch(handle: _lib.Handle, imgs: np.ndarray, config: dict, image_wid
     sw_px, min_px, max_px = graph_px_params(config, DOWNSAMPLE_WIDTH, image_width_microns)
     rows = (_lib.Row * n)()
     L = _lib.lib()
+    _lib.check(L.tmat_set_input_depth(handle.raw, int(input_bits)), "tmat_set_input_depth")
     args = (n, H, W, float(ds_ratio), DOWNSAMPLE_WIDTH, float(thresh[0]), float(thresh[1]), int(sw_px), int(min_px),
             int(max_px or 0), int(bool(config.get("remove_isolated_branches", False))), int(first_index), rows)
     if dev_ptr is None:
