@@ -46,7 +46,7 @@ def cpu_baseline(img, weights, handle, log, n_sample_patches=40):
     log(f"timing the CPU baseline (oracle port, PyTorch-CPU UNet, {cores} threads) on a bounded sample of one image")
     t = time.perf_counter
     t0 = t()
-    small = morph.lanczos4_resize_u16(img, morph.target_shape(img.shape, 0.625))
+    small = morph.lanczos4_resize_u16(img, morph.resized_shape(img.shape, 0.625))
     x = morph.rescale_intensity(small, (0, 1)).astype(np.float32)
     t_pre = t() - t0
     # tiles of the first D4 orientation (the same patches the reference feeds to keras predict)

@@ -74,7 +74,9 @@ int tmat_predict_smooth(tmat_handle h, const float *x, int n, int hh, int ww, do
 /*
  * compute_branches.py:309-328 for a batch: cv2.resize(img, round(shape * ds_ratio), INTER_LANCZOS4)
  * -> rescale_intensity(out_range=(0,1)).astype(f32) -> model.predict(auto_resample=False).
- * imgs: (n, H, W) u16; pred: (n, round(H*ds_ratio), round(W*ds_ratio)) f64.
+ * imgs: (n, H, W) u16; pred: (n, round(W*ds_ratio), round(H*ds_ratio)) f64 -- the reference passes its target shape to
+ * cv2.resize as dsize, which cv2 reads as (width, height), so rows and columns swap roles for non-square images
+ * (the later resize to the 384-wide field restores the aspect ratio); square images are unaffected.
  */
 int tmat_segment_batch(tmat_handle h, const uint16_t *imgs, int n, int H, int W, double ds_ratio, double *pred);
 

@@ -81,8 +81,16 @@ def lanczos4_resize_u16(img: np.ndarray, out_hw, sat: int = 65535) -> np.ndarray
 
 
 def target_shape(shape, ratio: float):
-    """tuple(np.round(np.multiply(img.shape[:2], ds_ratio)).astype(int))   :309-311"""
+    """tuple(np.round(np.multiply(img.shape[:2], ds_ratio)).astype(int))   :309-311 -- the tuple the reference hands to
+    cv2.resize as `dsize`.  cv2 reads dsize as (width, height), so the resized array has shape
+    resized_shape(shape, ratio) = (target_shape[1], target_shape[0]); the two agree for square images only."""
     return tuple(int(v) for v in np.round(np.multiply(shape[:2], ratio)).astype(int))
+
+
+def resized_shape(shape, ratio: float):
+    """(rows, cols) of cv2.resize(img, target_shape(...)) as the reference calls it   :309-312"""
+    ts = target_shape(shape, ratio)
+    return (ts[1], ts[0])
 
 
 # ------------------------------------------------------------------------------------------

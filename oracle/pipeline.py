@@ -28,7 +28,7 @@ def px_params(config: dict, field_width: int, image_width_microns: float):
 
 
 def segment(img_u16: np.ndarray, weights, ds_ratio=0.625, unet_kind="exact", patch=320, input_bits=16):
-    tgt = morph.target_shape(img_u16.shape, ds_ratio)
+    tgt = morph.resized_shape(img_u16.shape, ds_ratio)       # cv2's dsize is (width, height): see morph.target_shape
     small = morph.lanczos4_resize_u16(img_u16, tgt, sat=(1 << input_bits) - 1)
     x = morph.rescale_intensity(small, (0, 1)).astype(np.float32)
     pf = unet.predict_exact(weights) if unet_kind == "exact" else unet.predict_torch(weights)

@@ -181,3 +181,16 @@ def test_eight_bit_sources_saturate_at_255(handle, weights):
     assert row8[1:] == tuple(pipeline.analyze_image(wide, weights, CFG, 500.0, input_bits=8))
     row16 = branches.analyze_batch(handle, wide[None], CFG, 500.0)[0]             # and the default depth is restored per call
     assert row16[1:] == tuple(pipeline.analyze_image(wide, weights, CFG, 500.0))
+
+
+def test_nonsquare_segment_follows_cv2_dsize_order(handle, weights):
+    """compute_branches.py:309-312 passes (round(H r), round(W r)) to cv2.resize as dsize = (width, height): a 256 x 320
+    image becomes 200 rows x 160 columns before the network sees it"""
+    from oracle import morph, pipeline
+    from tmat_amd import _lib, synth
+    img = np.ascontiguousarray(synth.synth_image(11, 320, n_vessels=12)[:256])          # (256, 320)
+    assert morph.target_shape(img.shape, 0.625) == (160, 200) and morph.resized_shape(img.shape, 0.625) == (200, 160)
+    pred = np.empty((1, 200, 160), np.float64)
+    _lib.check(_lib.lib().tmat_segment_batch(handle.raw, _lib.ptr(img[None]), 1, 256, 320, 0.625, _lib.ptr(pred)), "segment")
+    want = pipeline.segment(img, weights)
+    assert want.shape == (200, 160) and np.array_equal(pred[0].view(np.uint64), want.view(np.uint64))

@@ -210,7 +210,11 @@ static void run_pass_host(Ctx *c, int slot, int k, const GraphParams gp, tmat_ro
 static int analyze_dev(Ctx *c, const uint16_t *imgs_dev, int n, int H, int W, double ds_ratio, int ds_width, GraphParams gp,
                        int64_t first_index, tmat_row *rows)
 {
-    const int h = round_half_even((double)H * ds_ratio), w = round_half_even((double)W * ds_ratio);
+    // compute_branches.py:309-312 hands target_shape = round(shape * ds_ratio) = (round(H r), round(W r)) to cv2.resize as
+    // dsize, which cv2 reads as (width, height): the resized image has round(W r) rows and round(H r) columns.  Square
+    // images are unaffected; for the others the network sees the reference's (anisotropically scaled) image and the
+    // later resize to (fh, fw) restores the aspect ratio, exactly as in the reference.
+    const int h = round_half_even((double)W * ds_ratio), w = round_half_even((double)H * ds_ratio);
     if (h < 1 || w < 1) { set_error("analyze: target shape is empty"); return TMAT_E_ARG; }
     gp.fh = round_half_even((double)H * ((double)ds_width / (double)W));
     gp.fw = round_half_even((double)W * ((double)ds_width / (double)W));
@@ -263,7 +267,7 @@ int tmat_segment_batch(tmat_handle hd, const uint16_t *imgs, int n, int H, int W
     if (!c || !imgs || !pred || n < 0 || H < 1 || W < 1) { set_error("tmat_segment_batch: bad argument"); return TMAT_E_ARG; }
     if (n == 0) return TMAT_OK;
     TMAT_HIP(hipSetDevice(c->device));
-    const int h = round_half_even((double)H * ds_ratio), w = round_half_even((double)W * ds_ratio);
+    const int h = round_half_even((double)W * ds_ratio), w = round_half_even((double)H * ds_ratio);    // see analyze_dev
     if (h < 1 || w < 1) { set_error("tmat_segment_batch: target shape is empty"); return TMAT_E_ARG; }
     TileGeom g = make_geom(h, w, c->patch);
     const int K = std::min(n, std::max(1, c->max_patches / g.tiles_per_img));
