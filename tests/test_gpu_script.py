@@ -88,3 +88,14 @@ def test_script_takes_the_width_from_tiff_metadata(tmp_path, handle):
         w = branches.analyze_batch(handle, imgs[k][None], cfg, width)[0]
         assert got[0] == k and int(got[1]) == w[1]
         assert float(got[2]) == pytest.approx(branches.pixels_to_microns(w[2], 384, width), rel=1e-12)
+
+
+def test_script_refuses_z_stacks(tmp_path):
+    """a directory of z-numbered slice sequences goes to the reference's Sato branch, which this path does not provide"""
+    from PIL import Image
+    ind = tmp_path / "in"
+    ind.mkdir()
+    for z in range(3):
+        Image.fromarray(np.zeros((64, 64), np.uint16)).save(ind / f"well_z{z}.tif")
+    r = run([str(ind), str(tmp_path / "o"), "--image-width-microns", "100"])
+    assert r.returncode == 1 and "Z stacks" in r.stdout

@@ -79,7 +79,10 @@ def load_image_2d(path: str, channel=None, time=None) -> np.ndarray:
         a = np.load(path)
     else:
         from PIL import Image
-        a = np.array(Image.open(path))
+        with Image.open(path) as im:
+            if getattr(im, "n_frames", 1) > 1:
+                raise ValueError(f"{path}: multi-page file (Z stack); project it first with compute_zproj.py")
+            a = np.array(im)
     if a.ndim == 3 and channel is not None:
         a = a[..., channel] if a.shape[-1] <= 4 else a[channel]
     if a.ndim != 2:
@@ -128,6 +131,18 @@ def main(args=None):
     if not paths:
         print(f"{FAIL}No images found in {in_root}", flush=True)
         sys.exit(1)
+    # The reference first looks for Z stacks (compute_branches.py:547-566): slice files with a z<number> token that form
+    # sequences of more than one slice, or multi-page files, go to its Sato branch, which is not part of this path.
+    from tmat_amd import zstacks as zs
+    try:
+        seqs = zs.find_zstack_image_sequences(str(in_root))
+        is_stack_dir = bool(seqs) and all(len(v) > 1 for v in seqs.values())
+    except zs.ZStackInputException:
+        is_stack_dir = False
+    if is_stack_dir:
+        print(f"{FAIL} {in_root} holds Z stacks (image sequences); the Z-stack branch of compute_branches is outside the "
+              "accelerated path. Project them first (compute_zproj.py) and analyse the projections.", flush=True)
+        sys.exit(1)
     # image_width_microns: the option / config key, else per image from the file's metadata (reference
     # compute_branches.py:184-212: img.shape[-1] * PhysicalPixelSizes.X), else the reference's failure message
     from tmat_amd import branches, distributed, models
@@ -150,7 +165,11 @@ def main(args=None):
     groups = {}
     for gi, img_id in enumerate(mine):
         print(f"Analyzing {img_id}...", flush=True)
-        img = load_image_2d(paths[img_id], args.channel, args.time)
+        try:
+            img = load_image_2d(paths[img_id], args.channel, args.time)
+        except (OSError, ValueError) as error:
+            print(f"{FAIL}{error}", flush=True)
+            sys.exit(1)
         width_um = config.get("image_width_microns")
         if width_um is None:
             px = helper.physical_pixel_sizes(paths[img_id]).X
