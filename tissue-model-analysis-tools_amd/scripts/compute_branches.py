@@ -155,6 +155,10 @@ def main(args=None):
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend)
     model = models.get_unet_patch_segmentor_from_cfg(model_cfg_path, device_id=local_rank)
+    if model.norm_mean is not None and model.norm_std is not None:
+        # models.py:636-637 normalises the image in predict(); the batched device path has no such stage
+        print(f"{FAIL} {model_cfg_path}: norm_mean / norm_std are not supported by the accelerated path.", flush=True)
+        sys.exit(1)
 
     ids = sorted(paths)
     mine = [ids[i] for i in distributed.shard_indices(len(ids), rank, ws)]
