@@ -1,8 +1,8 @@
 """CPU: oracle/morse.py against goldens produced by running the reference's topology.MorseGraph
-(tools/make_goldens.py morse; python 3.10, networkx 3.4.2 -- the reference pins networkx 3.3 whose
-_plain_bfs / subgraph-view iteration rules are the same).  Branch counts must be identical; lengths
-are compared at 1e-5 relative because the golden run used numpy 2.x, where python-int + float32
-stays float32 (the reference pins numpy 1.26.4, which the oracle's float64 accumulation follows)."""
+(tools/make_goldens.py morse, run under /opt/conda/bin/python3.9: numpy 1.26.4 -- the reference's pin, where
+python-int + float32 promotes to float64, so path lengths accumulate in float64 -- and networkx 2.6.3, whose
+_plain_bfs / subgraph-view iteration rules are those of the pinned 3.3).  Branch counts, every bar, the total and
+the average must be EQUAL (==), not close."""
 from pathlib import Path
 
 import numpy as np
@@ -36,6 +36,6 @@ def test_morse_matches_reference(name, ci):
     key = f"{name}_c{ci}"
     assert n == int(GM[key + "_count"])
     gb = GM[key + "_bars"].reshape(-1, 2)
-    np.testing.assert_allclose(np.array(bars, np.float64).reshape(-1, 2), gb, rtol=1e-5, atol=5e-3)
-    np.testing.assert_allclose(tot, float(GM[key + "_total"]), rtol=1e-5)
-    np.testing.assert_allclose(avg, float(GM[key + "_avg"]), rtol=1e-5)
+    assert np.array_equal(np.array(bars, np.float64).reshape(-1, 2), gb)
+    assert tot == float(GM[key + "_total"])
+    assert avg == float(GM[key + "_avg"])
