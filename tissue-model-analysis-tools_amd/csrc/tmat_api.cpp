@@ -148,6 +148,16 @@ static bool build_model(Ctx *c, const std::map<std::string, Tensor> &m)
             if (!need(m, sp + ".dw", dw) || !need(m, sp + ".pw", pw) || !need(m, sp + ".b", b) ||
                 !need(m, p + (s ? ".bn2" : ".bn1"), bn)) return false;
             fold_bn(bn, b, sc, sh);
+            {   // [9][C] -> [C/16][9][16]
+                const int C = (int)(dw.count / 9);
+                std::vector<float> q(dw.count);
+                if (C % 16 == 0) {
+                    for (int cb = 0; cb < C / 16; cb++)
+                        for (int tp = 0; tp < 9; tp++)
+                            for (int e = 0; e < 16; e++) q[((size_t)cb * 9 + tp) * 16 + e] = dw.data[(size_t)tp * C + cb * 16 + e];
+                    if (!upload(c, q, &d.dwq[s])) return false;
+                }
+            }
             if (!upload(c, std::vector<float>(dw.data, dw.data + dw.count), &d.dw[s]) ||
                 !upload(c, k_contiguous(pw.data, 1, pw.shape[0], pw.shape[1]), &d.pw[s]) || !upload(c, sc, &d.scale[s]) ||
                 !upload(c, sh, &d.shift[s])) return false;
@@ -244,6 +254,18 @@ int unet_down_dev(Ctx *c, const float *X, int n, float *dout, hipStream_t s)
     for (size_t bi = 0; bi < c->down.size(); bi++) {
         auto &d = c->down[bi];
         // prev = b0 (n, H, H, cin)
+        if (c->fused_sep && d.dwq[0] && d.dwq[1] && sepconv_supported(H, H, d.cin, d.cout) && sepconv_supported(H, H, d.cout, d.cout)) {
+            // stem output is already >= 0, so ReLU on load is the identity in the first block
+            if (!launch_sepconv(b0, n, H, H, d.cin, bi > 0, d.dwq[0], d.pw[0], d.cout, d.scale[0], d.shift[0], 1, b2, s) ||
+                !launch_sepconv(b2, n, H, H, d.cout, 0, d.dwq[1], d.pw[1], d.cout, d.scale[1], d.shift[1], 0, b3, s)) return TMAT_E_ARG;
+            ConvArgs r{};
+            r.in = b0; r.N = n; r.h = H; r.w = H; r.Cin = d.cin; r.ksize = 1; r.stride = 2; r.W = d.res_w; r.Cout = d.cout;
+            r.scale = nullptr; r.shift = d.res_b; r.out = b1;
+            if (!conv(c, r, s)) return TMAT_E_ARG;
+            launch_maxpool_add(b3, n, H, H, d.cout, b1, bi + 1 == c->down.size() ? dout : b0, s);
+            H /= 2;
+            continue;
+        }
         launch_dwconv(b0, n, H, H, d.cin, 1, d.dw[0], b1, s);
         ConvArgs a{};
         a.in = b1; a.N = n; a.h = H; a.w = H; a.Cin = d.cin; a.relu_in = 0; a.ksize = 1; a.stride = 1;
@@ -407,6 +429,7 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
     c->device = device_id;
     c->patch = patch;
     c->max_patches = max_patches > 0 ? max_patches : 400;
+    if (const char *e = getenv("TMAT_FUSED_SEP")) c->fused_sep = atoi(e) != 0;
     if (!hip_ok(hipStreamCreate(&c->stream), "hipStreamCreate") || !build_model(c, m)) { tmat_destroy((tmat_handle)c); return TMAT_E_WEIGHTS; }
     // activation workspace: per patch (P/2)^2 * f0 floats for buf0/buf1 and twice that for buf2/buf3
     const size_t unit = (size_t)(patch / 2) * (patch / 2) * c->f0;

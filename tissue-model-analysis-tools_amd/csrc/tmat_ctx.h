@@ -9,6 +9,7 @@ namespace tmat {
 struct DownBlock {
     int cin = 0, cout = 0;
     float *dw[2] = {nullptr, nullptr};      // [9][C]
+    float *dwq[2] = {nullptr, nullptr};     // the same taps as [C/16][9][16] for the fused separable kernel
     float *pw[2] = {nullptr, nullptr};      // [Cin][Cout]
     float *scale[2] = {nullptr, nullptr}, *shift[2] = {nullptr, nullptr};
     float *res_w = nullptr, *res_b = nullptr;
@@ -92,6 +93,7 @@ struct Ctx {
         }
         pass = PassBuf();
     }
+    bool fused_sep = true;                                   // fused depthwise->pointwise kernel where the level allows (TMAT_FUSED_SEP=0: off)
     // profiling of the dominant kernel family
     bool prof_on = false;
     std::vector<ProfEv> ev_open;

@@ -29,6 +29,10 @@ struct ConvArgs {
 };
 // returns false (and sets the error) on unsupported shapes
 bool launch_conv(const ConvArgs &a, hipStream_t s);
+// fused SeparableConv2D (sepconv_kernels.hip): depthwise taps dwq [Cin/16][9][16], pointwise pw [Cout][Cin]
+bool sepconv_supported(int H, int W, int Cin, int Cout);
+bool launch_sepconv(const float *in, int N, int H, int W, int Cin, int relu_in, const float *dwq, const float *pw, int Cout,
+                    const float *scale, const float *shift, int relu_out, float *out, hipStream_t s);
 void launch_dwconv(const float *in, int N, int H, int W, int C, int relu_in, const float *Wd, float *out, hipStream_t s);
 void launch_stem(const float *x, int N, int H, int W, const float *Ws, int Cout, const float *scale,
                  const float *shift, float *out, hipStream_t s);
