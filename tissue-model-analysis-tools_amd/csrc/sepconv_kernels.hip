@@ -17,127 +17,161 @@
 #include "tmat_internal.h"
 #include "../../include/tmat.h"
 
+#include <cstdlib>
+
 namespace tmat {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-// Geometry: one workgroup = 512 threads = 8 waves = a 16 x 16 pixel tile (M = 256) x 128 output channels.
+// Geometry: one workgroup = 512 threads = 8 waves; one TILE = a 16 x 16 pixel tile (M = 256) x 128 output channels.
 // Wave w owns tile rows 2w, 2w+1 (32 pixels) x 128 channels = four 32x32 accumulator tiles (64 VGPRs).
-// K chunk = 16 input channels = two 8-channel planes (g = 0, 1: the channel groups of the two MFMA k-quads).  LDS per
-// stage, in 16-byte cells:
+// One STEP = one K chunk of 16 input channels = two 8-channel planes (g = 0, 1: the channel groups of the two MFMA
+// k-quads).  Workgroups are PERSISTENT: each walks a contiguous range of (pixel tile, channel tile) pairs as one
+// stream of steps through a three-stage LDS ring, so the loads of the next tile run under the MFMAs of this one.
+// LDS per stage, in 16-byte cells:
+//   B    : [16 channels][128 output channels] f32 (n contiguous, filled from the [Cin][Cout] weights: one DMA piece =
+//          two channel rows); an MFMA's B value (channel 8g + 4h + e, column n) is ONE float per lane, read with
+//          ds_read_b32 (32 consecutive floats per half wave: conflict-free) one k step ahead of its MFMA
 //   halo : plane g at cell g * 704: 18 x 18 pixels x 2 cells (channel quads h = 0, 1), linear pitch 18; the cell of
 //          (pixel p, quad h) is 2 p + (h ^ ((p >> 3) & 1)); 11 DMA pieces of 64 cells per plane
-//   B    : plane g at cell g * 256: 128 output channels x 2 cells, cell of (row n, quad h) is 2 n + (h ^ ((n >> 3) & 1));
-//          4 DMA pieces per plane
 //   dw   : 9 taps x 4 cells (the depthwise taps of this channel block, [tap][16 channels]); 1 DMA piece
 // Every 16-lane service group of a ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32) must hit 16
-// distinct cells mod 16, i.e. 16 pixels (rows) that are distinct mod 16.  For B the rows of a group are distinct mod 16.
+// distinct cells mod 16, i.e. 16 pixels that are distinct mod 16.
 // For the halo the MFMA row index r = lane & 31 is mapped to tile pixels so that each service group is 16 consecutive
 // pixels of ONE tile row (PIXMAP below): their halo positions p are consecutive for every tap.
 // The plane split keeps g out of the swizzle: the g = 1 fragment sits at a constant byte offset from the g = 0 one
 // (an instruction immediate, no second set of address registers).
 // Everything reaches LDS by LDS-DMA (buffer_load_dwordx4 ... lds, lane-linear destination; the swizzle is applied to
-// the per-lane SOURCE address); the only synchronisation is vmcnt(0) + one barrier per chunk, two stages.
+// the per-lane SOURCE address).
+//
+// Pipeline (per wave, step s in stage s % 3; one vmcnt(0) + barrier per step):
+//   top of step s   : issue the DMA of step s + 2 into stage (s + 2) % 3 (last read in step s - 1, before that barrier)
+//   8 segments      : segment k = the 4 MFMAs of k step k (k-quad g = k / 4, element e = k % 4) interleaved with 12
+//                     depthwise FMAs; segments 0-2 finish the A fragment of THIS step's k-quad 1, segments 4-6 build
+//                     the A fragment of the NEXT step's k-quad 0 (its halo landed before the previous barrier); each
+//                     segment first issues the LDS reads the next segment consumes (two register sets), so no MFMA
+//                     group waits on LDS latency and all depthwise VALU work sits between MFMAs.
+//   end of step     : vmcnt(0) (the DMA issued at the top has had the whole step), barrier; after the last chunk of a
+//                     tile the accumulators are stored straight from registers (4 B per lane: one instruction writes
+//                     two full 128-byte lines) and cleared.
+// Measured alternatives (tools/build_variant.sh, in-kernel s_memtime stamps): the 8 MFMA segments of a step take
+// ~2500 cycles (2048 = the MFMAs alone).  Splitting the halo into four one-cell planes (no swizzle, one address
+// register) made every DMA piece touch 64 cache lines instead of 32 and the vector-memory issue queue became the
+// bottleneck (DMA issue 1300-3100 cycles per step); spreading the epilogue stores over the next tile's steps with a
+// counted vmcnt cost more in VALU and registers than the burst it removed.
+#ifndef SEP_WPS
+#define SEP_WPS 2
+#endif
 constexpr int SEP_KC = 16;
 constexpr int SEP_HPLANE = 11 * 64;                    // cells per halo plane
 constexpr int SEP_HALO_CELLS = 22 * 64;
 constexpr int SEP_B_CELLS = 8 * 64;
 constexpr int SEP_DW_CELLS = 64;
-// stage = [B | halo | dw]; 31 KiB, so that every (stage base + constant) of stage 1 fits the 16-bit ds_read offset field
-constexpr int SEP_B_OFF = 0, SEP_H_OFF = SEP_B_CELLS * 4, SEP_D_OFF = (SEP_B_CELLS + SEP_HALO_CELLS) * 4;      // float offsets
+// stage = [B | dw | halo]; 31 KiB, every (stage base + constant) of stages 0 and 1 fits the 16-bit ds_read offset field
+constexpr int SEP_B_OFF = 0, SEP_D_OFF = SEP_B_CELLS * 4, SEP_H_OFF = (SEP_B_CELLS + SEP_DW_CELLS) * 4;        // float offsets
 constexpr int SEP_STAGE_FLOATS = (SEP_HALO_CELLS + SEP_B_CELLS + SEP_DW_CELLS) * 4;
 
 struct SepArgs {
     const float *in;      // (N, H, W, Cin)
     int N, H, W, Cin, Cout;
     const float *dwq;     // depthwise taps, [Cin / 16][9][16]
-    const float *pw;      // pointwise weights [Cout][Cin]
+    const float *pw;      // pointwise weights [Cin][Cout] (the Keras layout)
     const float *scale, *shift;
     int relu_out;
     float *out;           // (N, H, W, Cout)
 };
 
+// PIXMAP: MFMA row rho (0..31) of wave w -> tile pixel (2w + yl, x)
+__device__ __forceinline__ int pixmap_y(int r) { return ((r >= 4 && r < 12) || (r >= 16 && r < 20) || r >= 28) ? 1 : 0; }
+__device__ __forceinline__ int pixmap_x(int r) { return r < 4 ? r : r < 12 ? r - 4 : r < 16 ? r - 8 : r < 20 ? r - 8 : r < 28 ? r - 12 : r - 16; }
+
 template <bool RELU_IN>
-// 2 workgroups (16 waves) per CU: second launch-bounds argument = waves per SIMD = 4 (<= 128 VGPRs)
-__global__ __launch_bounds__(512, 4) void sepconv_mfma_kernel(SepArgs a, int nMt, int nNt, int tiles_per_xcd)
+__global__ __launch_bounds__(512, SEP_WPS) void sepconv_mfma_kernel(SepArgs a, int nMt, int nNt, int G)
 {
     __shared__ __attribute__((aligned(16))) float stage0[SEP_STAGE_FLOATS];
     __shared__ __attribute__((aligned(16))) float stage1[SEP_STAGE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float stage2[SEP_STAGE_FLOATS];
 
-    // XCD-aware mapping: blocks b and b + 8 share an XCD; every XCD walks a contiguous range of pixel tiles (with their
-    // nNt channel tiles back to back), so the overlapping halos of neighbouring tiles are served by that XCD's L2.
+    // Persistent ranges: blocks b and b + 8 share an XCD; give every XCD a contiguous super-range of the (pixel tile,
+    // channel tile) pairs and every workgroup a contiguous piece of it, so the overlapping halos of neighbouring tiles
+    // and the re-read of a pixel tile by its nNt channel tiles are served by that XCD's L2.
     const int b = blockIdx.x;
-    const int xcd = b & 7, j = b >> 3;
-    const int nt = j % nNt;
-    const int mt = xcd * tiles_per_xcd + j / nNt;
-    if (mt >= nMt) return;
+    const int bp = (b & 7) * (G >> 3) + (b >> 3);
+    const long long P = (long long)nMt * nNt;
+    const int j0 = (int)(P * bp / G), j1 = (int)(P * (bp + 1) / G);
+    if (j0 >= j1) return;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int TW = a.W >> 4, TPP = (a.H >> 4) * TW;          // tiles per row / per patch
-    const int n = mt / TPP, tr = mt - n * TPP;
-    const int ty0 = (tr / TW) * 16, tx0 = (tr % TW) * 16;
-    const int n0 = nt * 128;
     const int Cin = a.Cin;
     const int nchunks = Cin / SEP_KC;
+    const int total = (j1 - j0) * nchunks;                   // steps of this workgroup
     constexpr unsigned OOB = 0x80000000u;
 
-    // ---- DMA roles --------------------------------------------------------------------------------------------
-    const __amdgpu_buffer_rsrc_t rsA =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + (size_t)n * a.H * a.W * Cin), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(a.pw + (size_t)n0 * Cin), 0, 0x7fffffff, 0x00020000);
+    // ---- DMA roles (tile-independent part) ------------------------------------------------------------------------
+    // B piece of this wave: channel rows 2 wave, 2 wave + 1 of the block; lane -> (row lane >> 5, columns 4 (lane & 31) ..):
+    // its offset is recomputed per step from the re-derived lane id (one register less across the loop)
+    const int bchunk = SEP_KC * a.Cout * 4;                  // bytes between channel blocks of the weights
     const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc((void *)a.dwq, 0, 0x7fffffff, 0x00020000);
-    unsigned hv[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const int q = (i * 8 + wave) * 64 + lane;            // destination cell of this lane
-        const int g = q >= SEP_HPLANE ? 1 : 0;
-        const int qq = q - g * SEP_HPLANE;
-        const int p = qq >> 1, d = qq & 1;
-        const int hy = p / 18, hx = p - hy * 18;
-        const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
-        const bool ok = p < 18 * 18 && Y >= 0 && Y < a.H && X >= 0 && X < a.W;
-        const int sg = 2 * g + (d ^ ((p >> 3) & 1));
-        hv[i] = ok ? (unsigned)((Y * a.W + X) * Cin + sg * 4) * 4u : OOB;
-    }
-    unsigned bvo;
-    {
-        const int q = wave * 64 + lane;
-        const int g = q >> 8, qq = q & 255;
-        const int nrow = qq >> 1, d = qq & 1;
-        const int sg = 2 * g + (d ^ ((nrow >> 3) & 1));
-        bvo = (unsigned)(nrow * Cin + sg * 4) * 4u;
-    }
-    const unsigned dvo = lane < 36 ? (unsigned)lane * 16u : OOB;
 
-#define SEP_ISSUE(stage_, chunk_)                                                                               \
+    // DMA iterator: the next step to load is (pair dj, chunk dc); its tile-dependent addressing:
+    int dj = j0, dc = 0, dleft = total;
+    unsigned hv[3];
+    const float *dA = a.in, *dB = a.pw;
+    auto dma_tile = [&](int jj) {
+        const int mt = jj / nNt, nt = jj - mt * nNt;
+        const int n = mt / TPP, tr = mt - n * TPP;
+        const int ty0 = (tr / TW) * 16, tx0 = (tr % TW) * 16;
+        dA = a.in + (size_t)n * a.H * a.W * Cin;
+        dB = a.pw + nt * 128;
+        // piece i * 8 + wave of 22: plane g = piece / 11, cells (piece % 11) * 64 + lane = (halo position, quad).  Recomputed
+        // per tile from an opaque copy of the lane id: kept in registers across the loop these would spill.
+        int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const int piece = i * 8 + wave;
+            const int g = piece / 11, qq = (piece - g * 11) * 64 + ln;
+            const int p = qq >> 1, d = qq & 1;
+            const int hy = p / 18, hx = p - hy * 18;
+            const int Y = ty0 - 1 + hy, X = tx0 - 1 + hx;
+            const bool ok = piece < 22 && p < 18 * 18 && Y >= 0 && Y < a.H && X >= 0 && X < a.W;
+            hv[i] = ok ? (unsigned)((Y * a.W + X) * Cin + (2 * g + (d ^ ((p >> 3) & 1))) * 4) * 4u : OOB;
+        }
+    };
+    dma_tile(dj);
+
+#define SEP_ISSUE(stage_)                                                                                       \
     {                                                                                                           \
         float *st = (stage_);                                                                                   \
-        const int so = (chunk_) * (SEP_KC * 4);                                                                 \
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)dA, 0, 0x7fffffff, 0x00020000); \
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void *)dB, 0, 0x7fffffff, 0x00020000); \
+        const int so = dc * (SEP_KC * 4);                                                                       \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t *)(st + SEP_H_OFF + (0 * 8 + wave) * 256), 16, hv[0], so, 0, 0); \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t *)(st + SEP_H_OFF + (1 * 8 + wave) * 256), 16, hv[1], so, 0, 0); \
         if (wave < 6)                                                                                           \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t *)(st + SEP_H_OFF + (2 * 8 + wave) * 256), 16, hv[2], so, 0, 0); \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t *)(st + SEP_B_OFF + wave * 256), 16, bvo, so, 0, 0); \
-        if (wave == 6 + ((chunk_) & 1))                                                                         \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_void_t *)(st + SEP_D_OFF), 16, dvo, (chunk_) * 576, 0, 0); \
+        const unsigned ln_ = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));                \
+        const unsigned bvo = ((2 * wave + (ln_ >> 5)) * a.Cout + (ln_ & 31) * 4) * 4u;                          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t *)(st + SEP_B_OFF + wave * 256), 16, bvo, dc * bchunk, 0, 0); \
+        if (wave == 6 + (dc & 1))                                                                               \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsD, (lds_void_t *)(st + SEP_D_OFF), 16, ln_ < 36 ? ln_ * 16u : OOB, dc * 576, 0, 0); \
+        dleft--;                                                                                                \
+        if (++dc == nchunks) { dc = 0; dj++; if (dleft > 0) dma_tile(dj); }                                     \
     }
 
-    // ---- fragment roles ---------------------------------------------------------------------------------------
-    // PIXMAP: MFMA row r = lane & 31 -> (tile row 2 wave + yl, column x): rows of one ds_read_b128 service group are 16
-    // consecutive pixels of one tile row.
+    // ---- fragment roles -------------------------------------------------------------------------------------------
     const int r = lane & 31, h = lane >> 5;
-    const int yl = ((r >= 4 && r < 12) || (r >= 16 && r < 20) || r >= 28) ? 1 : 0;
-    const int x = r < 4 ? r : r < 12 ? r - 4 : r < 16 ? r - 8 : r < 20 ? r - 8 : r < 28 ? r - 12 : r - 16;
+    const int yl = pixmap_y(r), x = pixmap_x(r);
     int hoff[9];            // BYTE offset of this lane's cell (quad h of plane 0) per tap; plane 1 is + SEP_HPLANE cells
 #pragma unroll
     for (int tp = 0; tp < 9; tp++) {
         const int p = (2 * wave + yl + tp / 3) * 18 + x + tp % 3;
         hoff[tp] = (SEP_H_OFF + (p * 2 + (h ^ ((p >> 3) & 1))) * 4) * 4;
     }
-    int boff = (SEP_B_OFF + (r * 2 + (h ^ ((r >> 3) & 1))) * 4) * 4;     // bytes; + jn * 1024 B, plane 1: + 4096 B
+    int boff = (SEP_B_OFF + 4 * h * 128 + r) * 4;        // bytes; + ((8 g + e) * 128 + 32 jn) * 4
     int doff = (SEP_D_OFF + h * 4) * 4;                  // bytes; + tap * 64 B, g = 1: + 32 B
 
     f32x16 acc[4];
@@ -145,58 +179,45 @@ __global__ __launch_bounds__(512, 4) void sepconv_mfma_kernel(SepArgs a, int nMt
     for (int jn = 0; jn < 4; jn++)
 #pragma unroll
         for (int e = 0; e < 16; e++) acc[jn][e] = 0.f;
+    // register sets: two (pixel quad, tap quad) triples for the depthwise rounds, two B quadruples for the k steps
+    float4 tvA[3], twA[3], tvB[3], twB[3];
+    float bqa[4], bqb[4];
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
 
-// One tap at a time (read the pixel's quad and the tap's quad, four FMAs); the loop-invariant lane offsets are made
-// opaque once per iteration so that hipcc keeps ONE set of them and folds the stage base and the plane / tap constants
-// into the ds_read offset field (hoisted, it materialises base + offset per stage and tap and spills).
-#define SEP_TAPS(st, g, t0)                                                                                     \
+#define SEP_RD(st, tv, tw, g, t0)                                                                               \
     _Pragma("unroll") for (int u = 0; u < 3; u++) {                                                             \
-        float4 v = *reinterpret_cast<const float4 *>(st + hoff[t0 + u] + g * (SEP_HPLANE * 16));                 \
-        const float4 w = *reinterpret_cast<const float4 *>(st + doff + (t0 + u) * 64 + g * 32);                  \
-        if (RELU_IN) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); } \
-        av.x = fmaf(v.x, w.x, av.x); av.y = fmaf(v.y, w.y, av.y);                                               \
-        av.z = fmaf(v.z, w.z, av.z); av.w = fmaf(v.w, w.w, av.w);                                               \
+        tv[u] = *reinterpret_cast<const float4 *>(st + hoff[t0 + u] + g * (SEP_HPLANE * 16));                   \
+        tw[u] = *reinterpret_cast<const float4 *>(st + doff + (t0 + u) * 64 + g * 32);                          \
     }
-#define SEP_STEP(cur, nxt, c_, more)                                                                            \
-    {                                                                                                           \
-        const char *st = reinterpret_cast<const char *>(cur);                                                   \
-        if (more) SEP_ISSUE(nxt, (c_) + 1)                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                      \
-        _Pragma("unroll") for (int g = 0; g < 2; g++) {                                                         \
-            float4 av = make_float4(0.f, 0.f, 0.f, 0.f);                                                        \
-            SEP_TAPS(st, g, 0) SEP_TAPS(st, g, 3) SEP_TAPS(st, g, 6)                                            \
-            float4 bv[4];                                                                                       \
-            _Pragma("unroll") for (int jn = 0; jn < 4; jn++)                                                    \
-                bv[jn] = *reinterpret_cast<const float4 *>(st + boff + g * 4096 + jn * 1024);                 \
-            _Pragma("unroll") for (int jn = 0; jn < 4; jn++) acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv[jn].x, acc[jn], 0, 0, 0); \
-            _Pragma("unroll") for (int jn = 0; jn < 4; jn++) acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv[jn].y, acc[jn], 0, 0, 0); \
-            _Pragma("unroll") for (int jn = 0; jn < 4; jn++) acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv[jn].z, acc[jn], 0, 0, 0); \
-            _Pragma("unroll") for (int jn = 0; jn < 4; jn++) acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv[jn].w, acc[jn], 0, 0, 0); \
-            __builtin_amdgcn_sched_barrier(0);                                                                  \
-        }                                                                                                       \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
-        __syncthreads();                                                                                        \
+#define SEP_FM(av, tv, tw)                                                                                      \
+    _Pragma("unroll") for (int u = 0; u < 3; u++) {                                                             \
+        if (RELU_IN) { tv[u].x = fmaxf(tv[u].x, 0.f); tv[u].y = fmaxf(tv[u].y, 0.f); tv[u].z = fmaxf(tv[u].z, 0.f); tv[u].w = fmaxf(tv[u].w, 0.f); } \
+        av.x = fmaf(tv[u].x, tw[u].x, av.x); av.y = fmaf(tv[u].y, tw[u].y, av.y);                               \
+        av.z = fmaf(tv[u].z, tw[u].z, av.z); av.w = fmaf(tv[u].w, tw[u].w, av.w);                               \
     }
+#define SEP_RB(st, bq, g, e)                                                                                    \
+    _Pragma("unroll") for (int jn = 0; jn < 4; jn++)                                                            \
+        bq[jn] = *reinterpret_cast<const float *>(st + boff + (((8 * g + e) * 128) + 32 * jn) * 4);
+#define SEP_MM(aval, bq)                                                                                        \
+    _Pragma("unroll") for (int jn = 0; jn < 4; jn++) acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval, bq[jn], acc[jn], 0, 0, 0);
+#define SEP_PIN() __builtin_amdgcn_sched_barrier(0);
+// inside a segment: LDS reads first, then MFMA / VALU alternating (one MFMA, a quarter of the segment's VALU work)
+#define SEP_MIX(nv)                                                                                             \
+    __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);                                                         \
+    _Pragma("unroll") for (int q_ = 0; q_ < 4; q_++) {                                                          \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x002, nv, 0);                                                     \
+    }
+    constexpr int NV = RELU_IN ? 6 : 3;
 
-    SEP_ISSUE(stage0, 0)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // even chunks live in stage0, odd ones in stage1 (nchunks is even: host check)
-    for (int c = 0; c < nchunks; c += 2) {
-#pragma unroll
-        for (int tp = 0; tp < 9; tp++) asm volatile("" : "+v"(hoff[tp]));
-        asm volatile("" : "+v"(boff), "+v"(doff));
-        SEP_STEP(stage0, stage1, c, true)
-        SEP_STEP(stage1, stage0, c + 1, c + 2 < nchunks)
-    }
-#undef SEP_STEP
-#undef SEP_TAPS
-#undef SEP_ISSUE
-
-    // ---- epilogue: straight from the accumulators.  C/D layout of the 32x32 tile: column = lane & 31 (output channel),
-    // row rho = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) (the MFMA row, i.e. PIXMAP's r).  One store instruction writes two
-    // full 128-byte lines (32 consecutive channels of two pixels).
-    {
+    // ---- epilogue of one tile: straight from the accumulators.  C/D layout of the 32x32 tile: column = lane & 31
+    // (output channel), row rho = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) (the MFMA row, i.e. PIXMAP's r).  One store
+    // instruction writes two full 128-byte lines (32 consecutive channels of two pixels).
+    auto store_tile = [&](int jj) {
+        const int mt = jj / nNt, nt = jj - mt * nNt;
+        const int n = mt / TPP, tr = mt - n * TPP;
+        const int ty0 = (tr / TW) * 16, tx0 = (tr % TW) * 16;
+        const int n0 = nt * 128;
         float *obase = a.out + ((size_t)n * a.H * a.W + (size_t)(ty0 + 2 * wave) * a.W + tx0) * a.Cout + n0 + r;
 #pragma unroll
         for (int jn = 0; jn < 4; jn++) {
@@ -204,38 +225,100 @@ __global__ __launch_bounds__(512, 4) void sepconv_mfma_kernel(SepArgs a, int nMt
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int rho = (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int pyl = ((rho >= 4 && rho < 12) || (rho >= 16 && rho < 20) || rho >= 28) ? 1 : 0;
-                const int px = rho < 4 ? rho : rho < 12 ? rho - 4 : rho < 16 ? rho - 8 : rho < 20 ? rho - 8 : rho < 28 ? rho - 12 : rho - 16;
                 float v = fmaf(acc[jn][e], sc, sh);
                 if (a.relu_out) v = fmaxf(v, 0.f);
-                obase[((size_t)pyl * a.W + px) * a.Cout + jn * 32] = v;
+                obase[((size_t)pixmap_y(rho) * a.W + pixmap_x(rho)) * a.Cout + jn * 32] = v;
+                acc[jn][e] = 0.f;
             }
         }
+    };
+
+#define SEP_STEP(SA, SB, SC)                                                                                    \
+    {                                                                                                           \
+        const char *sa = reinterpret_cast<const char *>(SA);                                                    \
+        const char *sb = reinterpret_cast<const char *>(SB);                                                    \
+        if (dleft > 0) SEP_ISSUE(SC)                                                                            \
+        SEP_PIN()                                                                                               \
+        a1 = make_float4(0.f, 0.f, 0.f, 0.f);                                                                   \
+        /* seg 0 */ SEP_RD(sa, tvB, twB, 1, 3) SEP_RB(sa, bqb, 0, 1) SEP_MM(a0.x, bqa) SEP_FM(a1, tvA, twA) SEP_MIX(NV) SEP_PIN() \
+        /* seg 1 */ SEP_RD(sa, tvA, twA, 1, 6) SEP_RB(sa, bqa, 0, 2) SEP_MM(a0.y, bqb) SEP_FM(a1, tvB, twB) SEP_MIX(NV) SEP_PIN() \
+        /* seg 2 */ SEP_RB(sa, bqb, 0, 3) SEP_MM(a0.z, bqa) SEP_FM(a1, tvA, twA) SEP_MIX(NV) SEP_PIN()          \
+        /* seg 3 */ SEP_RD(sb, tvB, twB, 0, 0) SEP_RB(sa, bqa, 1, 0) SEP_MM(a0.w, bqb) SEP_PIN()                \
+        a0 = make_float4(0.f, 0.f, 0.f, 0.f);       /* from here on: the A fragment of the NEXT step's k-quad 0 */ \
+        /* seg 4 */ SEP_RD(sb, tvA, twA, 0, 3) SEP_RB(sa, bqb, 1, 1) SEP_MM(a1.x, bqa) SEP_FM(a0, tvB, twB) SEP_MIX(NV) SEP_PIN() \
+        /* seg 5 */ SEP_RD(sb, tvB, twB, 0, 6) SEP_RB(sa, bqa, 1, 2) SEP_MM(a1.y, bqb) SEP_FM(a0, tvA, twA) SEP_MIX(NV) SEP_PIN() \
+        /* seg 6 */ SEP_RD(sb, tvA, twA, 1, 0) SEP_RB(sa, bqb, 1, 3) SEP_MM(a1.z, bqa) SEP_FM(a0, tvB, twB) SEP_MIX(NV) SEP_PIN() \
+        /* seg 7 */ SEP_RB(sb, bqa, 0, 0) SEP_MM(a1.w, bqb) SEP_PIN()                                           \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
+        __syncthreads();                                                                                        \
+        if (++cc == nchunks) { cc = 0; store_tile(cj); cj++; }                                                  \
+        if (--left == 0) break;                                                                                 \
     }
+
+    // ---- prologue: steps 0 and 1 in flight, then the A fragment of step 0's k-quad 0, the first round of its k-quad 1
+    // and the B values of its first k step
+    SEP_ISSUE(stage0)
+    if (dleft > 0) SEP_ISSUE(stage1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    {
+        const char *s0 = reinterpret_cast<const char *>(stage0);
+        SEP_RD(s0, tvA, twA, 0, 0) SEP_FM(a0, tvA, twA)
+        SEP_RD(s0, tvA, twA, 0, 3) SEP_FM(a0, tvA, twA)
+        SEP_RD(s0, tvA, twA, 0, 6) SEP_FM(a0, tvA, twA)
+        SEP_PIN()
+        SEP_RD(s0, tvA, twA, 1, 0) SEP_RB(s0, bqa, 0, 0)
+        SEP_PIN()
+    }
+
+    int cj = j0, cc = 0, left = total;      // compute iterator: pair, chunk, steps left
+    for (;;) {
+#pragma unroll
+        for (int tp = 0; tp < 9; tp++) asm volatile("" : "+v"(hoff[tp]));
+        asm volatile("" : "+v"(boff), "+v"(doff));
+        SEP_STEP(stage0, stage1, stage2)
+        SEP_STEP(stage1, stage2, stage0)
+        SEP_STEP(stage2, stage0, stage1)
+    }
+#undef SEP_STEP
+#undef SEP_MIX
+#undef SEP_RD
+#undef SEP_FM
+#undef SEP_RB
+#undef SEP_MM
+#undef SEP_PIN
+#undef SEP_ISSUE
 }
 
 bool sepconv_supported(int H, int W, int Cin, int Cout)
 {
-    return H % 16 == 0 && W % 16 == 0 && Cin % 32 == 0 && Cout % 128 == 0 && (long long)H * W * Cin * 4 < 0x7fffffffLL;
+    return H % 16 == 0 && W % 16 == 0 && Cin % 16 == 0 && Cout % 128 == 0 &&
+           (long long)H * W * Cin * 4 < 0x7fffffffLL && (long long)16 * W * Cout * 4 < 0x7fffffffLL;
 }
 
 // in (N, H, W, Cin) -> out (N, H, W, Cout): depthwise 3x3 (taps dwq [Cin/16][9][16], optional ReLU on load) ->
-// pointwise (pw [Cout][Cin]) -> fmaf(acc, scale, shift) -> optional ReLU
+// pointwise (pw [Cin][Cout]) -> fmaf(acc, scale, shift) -> optional ReLU
 bool launch_sepconv(const float *in, int N, int H, int W, int Cin, int relu_in, const float *dwq, const float *pw, int Cout,
                     const float *scale, const float *shift, int relu_out, float *out, hipStream_t s)
 {
-    if (!sepconv_supported(H, W, Cin, Cout) || N <= 0 || (long long)N * (H / 16) * (W / 16) > 0x3fffffffLL / 8) {
+    if (!sepconv_supported(H, W, Cin, Cout) || N <= 0 || (long long)N * (H / 16) * (W / 16) * (Cout / 128) > 0x3fffffffLL) {
         set_error("launch_sepconv: unsupported shape");
         return false;
     }
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 8) n_cu = 256;
+        else n_cu = prop.multiProcessorCount;
+    }
     SepArgs a{in, N, H, W, Cin, Cout, dwq, pw, scale, shift, relu_out, out};
     const int nMt = N * (H / 16) * (W / 16), nNt = Cout / 128;
-    const int tpx = (nMt + 7) / 8;
-    dim3 grid(8 * tpx * nNt);
+    const int G = (n_cu / 8) * 8;                 // one persistent workgroup per CU (93 KiB of LDS each)
     if (relu_in)
-        hipLaunchKernelGGL(sepconv_mfma_kernel<true>, grid, dim3(512), 0, s, a, nMt, nNt, tpx);
+        hipLaunchKernelGGL(sepconv_mfma_kernel<true>, dim3(G), dim3(512), 0, s, a, nMt, nNt, G);
     else
-        hipLaunchKernelGGL(sepconv_mfma_kernel<false>, grid, dim3(512), 0, s, a, nMt, nNt, tpx);
+        hipLaunchKernelGGL(sepconv_mfma_kernel<false>, dim3(G), dim3(512), 0, s, a, nMt, nNt, G);
     return true;
 }
 

@@ -155,7 +155,7 @@ static bool build_model(Ctx *c, const std::map<std::string, Tensor> &m)
                     for (int cb = 0; cb < C / 16; cb++)
                         for (int tp = 0; tp < 9; tp++)
                             for (int e = 0; e < 16; e++) q[((size_t)cb * 9 + tp) * 16 + e] = dw.data[(size_t)tp * C + cb * 16 + e];
-                    if (!upload(c, q, &d.dwq[s])) return false;
+                    if (!upload(c, q, &d.dwq[s]) || !upload(c, std::vector<float>(pw.data, pw.data + pw.count), &d.pwT[s])) return false;
                 }
             }
             if (!upload(c, std::vector<float>(dw.data, dw.data + dw.count), &d.dw[s]) ||
@@ -256,8 +256,8 @@ int unet_down_dev(Ctx *c, const float *X, int n, float *dout, hipStream_t s)
         // prev = b0 (n, H, H, cin)
         if (c->fused_sep && d.dwq[0] && d.dwq[1] && sepconv_supported(H, H, d.cin, d.cout) && sepconv_supported(H, H, d.cout, d.cout)) {
             // stem output is already >= 0, so ReLU on load is the identity in the first block
-            if (!launch_sepconv(b0, n, H, H, d.cin, bi > 0, d.dwq[0], d.pw[0], d.cout, d.scale[0], d.shift[0], 1, b2, s) ||
-                !launch_sepconv(b2, n, H, H, d.cout, 0, d.dwq[1], d.pw[1], d.cout, d.scale[1], d.shift[1], 0, b3, s)) return TMAT_E_ARG;
+            if (!launch_sepconv(b0, n, H, H, d.cin, bi > 0, d.dwq[0], d.pwT[0], d.cout, d.scale[0], d.shift[0], 1, b2, s) ||
+                !launch_sepconv(b2, n, H, H, d.cout, 0, d.dwq[1], d.pwT[1], d.cout, d.scale[1], d.shift[1], 0, b3, s)) return TMAT_E_ARG;
             ConvArgs r{};
             r.in = b0; r.N = n; r.h = H; r.w = H; r.Cin = d.cin; r.ksize = 1; r.stride = 2; r.W = d.res_w; r.Cout = d.cout;
             r.scale = nullptr; r.shift = d.res_b; r.out = b1;

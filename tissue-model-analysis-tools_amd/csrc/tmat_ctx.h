@@ -10,7 +10,8 @@ struct DownBlock {
     int cin = 0, cout = 0;
     float *dw[2] = {nullptr, nullptr};      // [9][C]
     float *dwq[2] = {nullptr, nullptr};     // the same taps as [C/16][9][16] for the fused separable kernel
-    float *pw[2] = {nullptr, nullptr};      // [Cin][Cout]
+    float *pw[2] = {nullptr, nullptr};      // [Cout][Cin] (k contiguous, conv_mfma_kernel)
+    float *pwT[2] = {nullptr, nullptr};     // [Cin][Cout] (fused separable kernel)
     float *scale[2] = {nullptr, nullptr}, *shift[2] = {nullptr, nullptr};
     float *res_w = nullptr, *res_b = nullptr;
 };

@@ -29,7 +29,7 @@ struct ConvArgs {
 };
 // returns false (and sets the error) on unsupported shapes
 bool launch_conv(const ConvArgs &a, hipStream_t s);
-// fused SeparableConv2D (sepconv_kernels.hip): depthwise taps dwq [Cin/16][9][16], pointwise pw [Cout][Cin]
+// fused SeparableConv2D (sepconv_kernels.hip): depthwise taps dwq [Cin/16][9][16], pointwise pwT [Cin][Cout]
 bool sepconv_supported(int H, int W, int Cin, int Cout);
 bool launch_sepconv(const float *in, int N, int H, int W, int Cin, int relu_in, const float *dwq, const float *pw, int Cout,
                     const float *scale, const float *shift, int relu_out, float *out, hipStream_t s);
