@@ -33,67 +33,86 @@ SIZE = 1024
 MFMA_F32_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: f32-input MFMA = vector f32 peak
 
 
-def cpu_baseline(img, weights, handle, log, n_sample_patches=40):
-    """Reference CPU path = the oracle port (UNet on all usable cores -- both the as-written PyTorch-CPU graph and the
-    oracle's own C/OpenMP implementation are timed and the faster counts -- + the oracle's numpy/C host stages), timed
-    on a BOUNDED sample of one 1024x1024 image of the workload: all non-UNet stages in full, the UNet on
-    `n_sample_patches` of the image's 200 patches (scaled up)."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(img, weights, handle, log, n_sample_patches=40, repeats=3):
+    """Reference CPU path = the oracle port (UNet on all usable cores + the oracle's numpy/C host stages), timed on a
+    BOUNDED sample of one 1024x1024 image of the workload: all non-UNet stages in full, the UNet on `n_sample_patches`
+    of the image's 200 patches (scaled up).  Every stage is timed `repeats` times and the MEDIAN counts.  Two CPU UNet
+    implementations exist in the oracle (the as-written PyTorch-CPU graph, and oracle/unet_exact.c with OpenMP and the
+    sub-pixel form); the faster one is the baseline, the other is reported (timed once: it is 3x slower)."""
+    import statistics
     import torch
     from oracle import blend, dmt, morph, morse, pipeline, unet as ou
     from tmat_amd import _lib
     cores = ou.usable_cores()
     torch.set_num_threads(cores)
-    log(f"timing the CPU baseline (oracle port, PyTorch-CPU UNet, {cores} threads) on a bounded sample of one image")
+    log(f"timing the CPU baseline (oracle port, {cores} threads, median of {repeats}) on a bounded sample of one image")
     t = time.perf_counter
-    t0 = t()
-    small = morph.lanczos4_resize_u16(img, morph.resized_shape(img.shape, 0.625))
-    x = morph.rescale_intensity(small, (0, 1)).astype(np.float32)
-    t_pre = t() - t0
+
+    def med(fn, n=repeats):
+        ts = []
+        for _ in range(n):
+            t0 = t(); r = fn(); ts.append(t() - t0)
+        return statistics.median(ts), r
+
+    def pre():
+        small = morph.lanczos4_resize_u16(img, morph.resized_shape(img.shape, 0.625))
+        return morph.rescale_intensity(small, (0, 1)).astype(np.float32)
+    t_pre, x = med(pre)
     # tiles of the first D4 orientation (the same patches the reference feeds to keras predict)
     pad = np.pad(x, 160, constant_values=x.min())
     tiles = np.array([pad[i:i + 320, j:j + 320] for i in range(0, 641, 160) for j in range(0, 641, 160)])
-    ou.forward_torch(weights, tiles[:2])                      # warm the thread pool
-    t0 = t()
-    done = 0
-    while done < n_sample_patches:
-        k = min(16, n_sample_patches - done)                  # INFERENCE_BATCH_SIZE = 16
-        ou.forward_torch(weights, tiles[(np.arange(k) + done) % len(tiles)])
-        done += k
-        log(f"  cpu baseline: {done}/{n_sample_patches} sample patches")
-    t_unet_torch = (t() - t0) * (200.0 / n_sample_patches)
-    # the same sample through the oracle's own UNet (oracle/unet_exact.c: OpenMP, fixed-order FMA chains, sub-pixel form)
-    ou.forward_exact(weights, tiles[:2])
-    t0 = t()
-    done = 0
-    while done < n_sample_patches:
-        k = min(16, n_sample_patches - done)
-        ou.forward_exact(weights, tiles[(np.arange(k) + done) % len(tiles)])
-        done += k
-    t_unet_exact = (t() - t0) * (200.0 / n_sample_patches)
-    log(f"  cpu baseline: UNet per image {t_unet_torch:.2f}s (PyTorch-CPU, as written) / {t_unet_exact:.2f}s (oracle C, OpenMP)")
+
+    def unet(fwd):
+        done = 0
+        while done < n_sample_patches:
+            k = min(16, n_sample_patches - done)                  # INFERENCE_BATCH_SIZE = 16
+            fwd(weights, tiles[(np.arange(k) + done) % len(tiles)])
+            done += k
+    ou.forward_exact(weights, tiles[:2])                          # warm the thread pool / page in the weights
+    t_exact, _ = med(lambda: unet(ou.forward_exact))
+    t_unet_exact = t_exact * (200.0 / n_sample_patches)
+    ou.forward_torch(weights, tiles[:2])
+    t_torch, _ = med(lambda: unet(ou.forward_torch), 1)
+    t_unet_torch = t_torch * (200.0 / n_sample_patches)
+    log(f"  cpu baseline: UNet per image {t_unet_torch:.2f}s (PyTorch-CPU, as written, 1 run) / {t_unet_exact:.2f}s (oracle C, OpenMP, median)")
     t_unet = min(t_unet_torch, t_unet_exact)                  # the baseline is the faster CPU implementation
-    t0 = t()
-    blend.predict_img_with_smooth_windowing(x, 320, 2, lambda b, verbose=0: np.asarray(b)[..., None])
-    t_blend = t() - t0
+    t_blend, _ = med(lambda: blend.predict_img_with_smooth_windowing(x, 320, 2, lambda b, verbose=0: np.asarray(b)[..., None]))
     # downstream stages on the probability map of the same image (taken from the GPU path)
     pred = np.empty((1,) + x.shape, np.float64)
     _lib.check(_lib.lib().tmat_segment_batch(handle.raw, _lib.ptr(np.ascontiguousarray(img[None])), 1, img.shape[0], img.shape[1],
                                              0.625, _lib.ptr(pred)), "segment")
-    t0 = t()
-    field, _, _ = morph.postprocess(pred[0], morph.dsamp_shape(img.shape, 384))
-    f255 = morph.rescale_intensity(field, (0, 255))
-    V, E = dmt.compute_dmt_graph(f255, 5.0, 10.0)
-    sw, mn, mx = pipeline.px_params(CFG, 384, IMAGE_WIDTH_MICRONS)
-    _, n0, tot0, _ = morse.morse_stats(V, E, field.shape, sw, mn, mx, False, None)
-    t_post = t() - t0
+
+    def post():
+        field, _, _ = morph.postprocess(pred[0], morph.dsamp_shape(img.shape, 384))
+        f255 = morph.rescale_intensity(field, (0, 255))
+        V, E = dmt.compute_dmt_graph(f255, 5.0, 10.0)
+        sw, mn, mx = pipeline.px_params(CFG, 384, IMAGE_WIDTH_MICRONS)
+        return morse.morse_stats(V, E, field.shape, sw, mn, mx, False, None)[1]
+    t_post, n0 = med(post)
     total = t_pre + t_unet + t_blend + t_post
     log(f"  cpu baseline: pre {t_pre:.2f}s unet(scaled) {t_unet:.2f}s blend {t_blend:.2f}s post+graph {t_post:.2f}s")
     return {"value": round(1.0 / total, 5), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"one 1024x1024 image: all non-UNet stages in full; UNet on {n_sample_patches} of its 200 patches "
-                      f"(time scaled by 200/{n_sample_patches}) with both CPU implementations of the oracle, the faster one counted",
+            "sample": f"one 1024x1024 image, every stage the median of {repeats} runs: all non-UNet stages in full; UNet on "
+                      f"{n_sample_patches} of its 200 patches (time scaled by 200/{n_sample_patches}) with the faster of the oracle's two CPU implementations",
+            "cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(), "torch_threads": int(torch.get_num_threads()),
             "seconds_per_image": round(total, 2), "unet_seconds_per_image": round(t_unet, 2),
             "unet_seconds_per_image_torch_as_written": round(t_unet_torch, 2),
             "unet_seconds_per_image_oracle_c": round(t_unet_exact, 2), "count": int(n0)}
+
+
+def _gen_image(i):
+    from tmat_amd import synth
+    return synth.synth_image(i, SIZE)
 
 
 def main():
@@ -102,7 +121,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--images", type=int, default=256, help="images per GPU per step")
-    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic images generated (tiled to --images)")
+    ap.add_argument("--distinct", type=int, default=0, help="distinct synthetic images generated (0 = all of them, SURVEY 8d; fewer are tiled)")
     ap.add_argument("--max-patches", type=int, default=1600, help="UNet patches resident per pass (200 per image)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -118,7 +137,21 @@ def main():
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
         ncpu = os.cpu_count() or 8
-    os.environ.setdefault("TMAT_HOST_THREADS", str(max(1, min(ncpu // max(1, world), 32))))
+    os.environ.setdefault("TMAT_HOST_THREADS", str(max(1, min(ncpu // max(1, world), 32))))      # = distributed.host_threads_per_rank
+
+    # synthetic inputs (image i of rank r from RandomState(1234 + r * 100003 + i)), generated by a process pool
+    # BEFORE anything touches the GPU (fork after HIP initialisation is not safe)
+    n_img = args.images
+    n_distinct = n_img if args.distinct <= 0 else min(args.distinct, n_img)
+    t_gen = time.perf_counter()
+    workers = max(1, min(ncpu // max(1, world), 32, n_distinct))
+    if workers > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(workers) as pool:
+            distinct = pool.map(_gen_image, [rank * 100003 + i for i in range(n_distinct)], chunksize=1)
+    else:
+        distinct = [_gen_image(rank * 100003 + i) for i in range(n_distinct)]
+    t_gen = time.perf_counter() - t_gen
 
     import torch
     dist = None
@@ -133,9 +166,7 @@ def main():
     handle = _lib.Handle(synth.pack_weights(weights), local_rank, args.max_patches)
     L = _lib.lib()
 
-    # synthetic inputs, resident in HBM before the timed region (each rank gets its own images)
-    n_img = args.images
-    distinct = [synth.synth_image(rank * 100003 + i, SIZE) for i in range(min(args.distinct, n_img))]
+    # resident in HBM before the timed region (each rank has its own images)
     host = np.stack([distinct[i % len(distinct)] for i in range(n_img)])
     dptr = ctypes.c_void_p()
     _lib.check(L.tmat_dev_alloc(handle.raw, host.nbytes, ctypes.byref(dptr)), "dev_alloc")
@@ -158,12 +189,11 @@ def main():
         if rank == 0:
             print(f"[bench +{time.perf_counter() - t_start:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
-    log(f"inputs resident in HBM ({n_img} images/GPU), starting {args.warmup} warmup step(s)")
+    log(f"{n_distinct} distinct images generated in {t_gen:.1f}s by {workers} processes; inputs resident in HBM ({n_img} images/GPU), "
+        f"starting {args.warmup} warmup step(s)")
     for _ in range(args.warmup):
         rows = step()
     log("warmup done, timing")
-    handle.prof_enable(True)
-    handle.prof_read(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -171,10 +201,18 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     log(f"timed region {elapsed:.2f} s")
+    # HIP-event timing of the dominant kernel in a SEPARATE pass after the timed region (same kernels, same 1600-patch
+    # launches: two passes of 8 images), on the stream the kernels are launched on.  Its rows double as a determinism /
+    # race screen: the same images in another position of another run must give identical rows; tiled copies likewise.
+    n_prof = min(16, n_img)
+    handle.prof_enable(True)
+    handle.prof_read(True)
+    prof_rows = branches.analyze_batch(handle, (n_prof, SIZE, SIZE), CFG, IMAGE_WIDTH_MICRONS, first_index=rank * n_img, dev_ptr=dptr.value)
     conv_ms, conv_launches, conv_flops = handle.prof_read(True)
     handle.prof_enable(False)
-    # copies of the same synthetic image sit in different passes / positions of the batch: their rows must be identical
-    # (a cheap whole-run determinism / race screen of the timed output itself)
+    for i in range(n_prof):
+        if prof_rows[i][1:] != rows[i][1:]:
+            raise SystemExit(f"bench: image {i} gave different rows in two runs: {prof_rows[i]} vs {rows[i]}")
     nd = len(distinct)
     for i, r in enumerate(rows):
         if r[1:] != rows[i % nd][1:]:
@@ -184,11 +222,9 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        # the one collective of the path: all-gather of the 32-byte result rows over RCCL/xGMI
-        mine = torch.tensor([[r[0], r[1], r[2], r[3]] for r in rows], dtype=torch.float64, device="cuda")
-        allrows = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(allrows, mine)
-        n_rows = sum(int(a.shape[0]) for a in allrows)
+        # the one collective of the path: a single fixed-size all-gather of the 32-byte result rows over RCCL/xGMI
+        from tmat_amd import distributed
+        n_rows = len(distributed.gather_rows(rows, n_total=n_img * world))
     else:
         n_rows = len(rows)
 
@@ -200,23 +236,35 @@ def main():
         # HBM traffic of the dominant kernel comes from the committed PMC summary of the same pipeline (separate
         # rocprofv3 --pmc passes, tools/profile_round.sh); it is per launch of 1600 patches, like `achieved`
         traffic = None
+        top_by_time = None
         summ = sorted((REPO / "profiles").glob("r*_summary.json"))
         if summ and args.max_patches == 1600:
-            traffic = json.loads(summ[-1].read_text()).get("traffic_bytes_per_launch")
+            sj = json.loads(summ[-1].read_text())
+            traffic = sj.get("traffic_bytes_per_launch")
+            top_by_time = sj.get("top_kernels_by_total_time")
+        # path-level figure: every FLOP the step runs on the matrix cores (all 3x3 / sub-pixel / 1x1 layers) over the
+        # whole step time (which also holds the vector-ALU layers, morphology, blending and the host stages)
+        path_flops = synth.mfma_flops_per_patch() * 200.0 * n_img * world * args.steps
+        path_tflops = path_flops / elapsed / 1e12 / world
         out = {
             "metric": "images/sec (1024x1024 uint16) through compute_branches",
             "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{n_img} synthetic 1024x1024 uint16 Z-projections per GPU ({len(distinct)} distinct, tiled), "
-                                   "tiled UNet seg (200 patches/image, random-init structured weights) + DMT branch extraction, "
-                                   "default_branching_computation.json", "images_per_gpu": n_img, "patches_per_image": 200,
+            "config": {"workload": f"{n_img} synthetic 1024x1024 uint16 Z-projections per GPU ({len(distinct)} distinct), inputs pre-resident "
+                                   "in HBM (host-pointer entry adds 2 MB/image of H2D), tiled UNet seg (200 patches/image, random-init "
+                                   "structured weights) + DMT branch extraction, default_branching_computation.json",
+                       "images_per_gpu": n_img, "distinct_images": len(distinct), "patches_per_image": 200,
                        "rows_gathered": n_rows, "copies_identical": True, "host_threads": int(os.environ["TMAT_HOST_THREADS"])},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                          "kernel": "tmat::conv_mfma_kernel<128, 128, 4, 2, 3, false> (3x3 implicit-GEMM on v_mfma_f32_32x32x2_f32; "
-                                   "3 of the 8 transposed-conv layers, 39 % of the 3x3 / sub-pixel MFMA FLOPs)",
-                         "launches": int(conv_launches), "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4)},
+                                   "3 of the 8 transposed-conv layers, 39 % of the 3x3 / sub-pixel MFMA FLOPs; the largest kernel by total time)",
+                         "launches": int(conv_launches), "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
+                         "timed_in": f"separate pass of {n_prof} images after the timed region (HIP events on the launch stream)",
+                         "path_achieved": round(path_tflops, 2), "path_frac": round(path_tflops / MFMA_F32_PEAK_TFLOPS, 4),
+                         "path_note": "executed MFMA FLOPs of the whole step (19.08 GFLOP/patch: every 3x3 / sub-pixel / 1x1 layer) / ms_per_step, per GPU",
+                         "top_kernels_by_total_time": top_by_time},
         }
         sample = [r for r in rows[:4]]
         out["config"]["sample_rows"] = [[int(r[0]), int(r[1]), round(r[2], 3)] for r in sample]

@@ -25,8 +25,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   m = flattened (n, y, x) output pixel.  Both operands live in LDS as [row][32 channels] images (128-byte rows,
 //   k contiguous -- the NHWC layout of the activations and the [tap][Cout][Cin] layout of the weights), filled by
 //   LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR staging, no ds_write pass).  The 16-byte slot p of row r holds the
-//   channel group p ^ (r & 7): the DMA destination is lane-linear, so the swizzle is applied to the per-lane SOURCE
-//   address, and to the slot index on the read side; fragments are read with ds_read_b128, conflict-free.
+//   channel group p ^ ((r >> 1) & 7): the DMA destination is lane-linear, so the swizzle is applied to the per-lane SOURCE
+//   address, and to the slot index on the read side; fragments are read with ds_read_b128.  A ds_read_b128 is served in
+//   16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32); the 16 rows of a group are distinct mod 16, so
+//   (row & 1, slot ^ ((row >> 1) & 7)) names 16 distinct 16-byte bank groups: conflict-free (with the key r & 7 of round 1,
+//   rows 12 and 20 of a group shared a bank group: SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE).
 //   One K chunk = one (32-channel block, tap); out-of-image taps are out-of-range buffer offsets (zeros).  Two LDS stages: the DMA of chunk
 //   c+1 is issued before the MFMAs of chunk c and retired (vmcnt(0)) at the single barrier that ends chunk c.
 //   256 threads = 4 waves arranged WM x WN, each wave owns (BM/WM) x (BN/WN) outputs as TM x TN tiles of 32x32.
@@ -84,14 +87,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
     const int cchunks = a.Cin / KC;
     const int nchunks = taps * cchunks;
 
-    // DMA role of this lane: row (t >> 3) of every RP-row pass, slot t & 7, i.e. channel group (t & 7) ^ (row & 7).
+    // DMA role of this lane: row (t >> 3) of every RP-row pass, slot t & 7, i.e. channel group (t & 7) ^ ((row >> 1) & 7).
     // The DMA is a raw buffer load (buffer_load_dwordx4 ... lds): address = buffer base + per-lane voffset + scalar
     // soffset.  The A buffer starts (w + 1) stored pixels before the tile's first pixel, the per-lane voffset is the
     // pixel's distance from that first pixel (fixed for the whole kernel), and the tap / channel-block displacement
     // ((dy + 1) w + dx + 1) Cin + 32 cb is the scalar soffset: no per-chunk 64-bit address math.  Out-of-image taps (and
     // rows past M) use a voffset beyond num_records: the buffer range check makes the load return zeros.
     const int srow = t >> 3;
-    const int c4 = ((t & 7) ^ (srow & 7)) * 4;
+    const int c4 = ((t & 7) ^ ((srow >> 1) & 7)) * 4;
     constexpr unsigned OOB = 0x80000000u;
     // pointwise, stride 1: the stored pixel of output m is m itself -- no index arithmetic at all (these layers have
     // K = Cin as small as 64, i.e. two chunks per tile, so a division-heavy prologue would show)
@@ -179,11 +182,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][jn][r] = 0.f;
 
-    // fragment addressing: row = tile base + (lane & 31) (tile bases are multiples of 8, so the swizzle key is lane & 7),
-    // slot of channel group 2g + (lane >> 5) is (2g + (lane >> 5)) ^ (lane & 7)
+    // fragment addressing: row = tile base + (lane & 31) (tile bases are multiples of 32, so the swizzle key is (lane >> 1) & 7),
+    // slot of channel group 2g + (lane >> 5) is (2g + (lane >> 5)) ^ key
     const int arow = (wm * (BM / WM) + (lane & 31)) * KC;
     const int brow = (BM + wn * (BN / WN) + (lane & 31)) * KC;
-    const int hi = lane >> 5, key = lane & 7;
+    const int hi = lane >> 5, key = (lane >> 1) & 7;
 
     // ReLU on a fragment register: as a signed integer a negative float (and -0.0) is negative, so one v_max_i32 with 0
     // gives relu(x) = x > 0 ? x : +0.0 exactly (no NaNs here), without fmaxf's canonicalisation.

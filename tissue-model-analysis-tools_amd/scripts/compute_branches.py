@@ -75,6 +75,10 @@ def create_output_csv(output_file: Path):
 
 
 def load_image_2d(path: str, channel=None, time=None) -> np.ndarray:
+    """One 2-D plane of an image file (reference helper.load_image :23-95 returns ZYX / YX for the chosen T and C).
+    Time series are outside this path: a --time other than 0 is refused, as compute_zproj.py does."""
+    if time not in (None, 0):
+        raise ValueError(f"{path}: --time {time}: time series are not supported by the accelerated path (only T = 0)")
     if path.endswith(".npy"):
         a = np.load(path)
     else:
@@ -83,8 +87,19 @@ def load_image_2d(path: str, channel=None, time=None) -> np.ndarray:
             if getattr(im, "n_frames", 1) > 1:
                 raise ValueError(f"{path}: multi-page file (Z stack); project it first with compute_zproj.py")
             a = np.array(im)
-    if a.ndim == 3 and channel is not None:
-        a = a[..., channel] if a.shape[-1] <= 4 else a[channel]
+    if a.ndim == 3:
+        # interleaved (H, W, C) as PIL decodes RGB(A) files, or planar (C, H, W) arrays: the channel axis is the one of
+        # length <= 4; anything else is ambiguous and refused rather than guessed
+        cax = [ax for ax in (2, 0) if a.shape[ax] <= 4]
+        if not cax:
+            raise ValueError(f"{path}: cannot tell the channel axis of shape {a.shape}")
+        if channel is None:
+            if a.shape[cax[0]] != 1:
+                raise ValueError(f"{path}: {a.shape[cax[0]]} channels, pass --channel")
+            channel = 0
+        if not 0 <= channel < a.shape[cax[0]]:
+            raise ValueError(f"{path}: --channel {channel} out of range for shape {a.shape}")
+        a = np.take(a, channel, axis=cax[0])
     if a.ndim != 2:
         raise ValueError(f"{path}: expected a single-channel 2-D image, got shape {a.shape}")
     if a.dtype not in (np.uint8, np.uint16):
@@ -145,8 +160,10 @@ def main(args=None):
         sys.exit(1)
     # image_width_microns: the option / config key, else per image from the file's metadata (reference
     # compute_branches.py:184-212: img.shape[-1] * PhysicalPixelSizes.X), else the reference's failure message
-    from tmat_amd import branches, distributed, models
+    from tmat_amd import branches, distributed, helper, models
     ws, rank, local_rank = distributed.world()
+    # host stages (thinning, DMT, MorseGraph) run on worker threads of every rank: share the cores between the ranks
+    os.environ.setdefault("TMAT_HOST_THREADS", str(distributed.host_threads_per_rank(ws)))
     if ws > 1:
         import torch
         import torch.distributed as dist
@@ -160,20 +177,19 @@ def main(args=None):
         print(f"{FAIL} {model_cfg_path}: norm_mean / norm_std are not supported by the accelerated path.", flush=True)
         sys.exit(1)
 
+    # ids are file stems, as in the reference (compute_branches.py:565-569: two files with one stem are one entry there too)
     ids = sorted(paths)
-    mine = [ids[i] for i in distributed.shard_indices(len(ids), rank, ws)]
-    grid = branches.threshold_grid(config)
-    results = {suffix: [] for _, suffix in grid}
-    # batch images of equal shape and physical width
-    from tmat_amd import helper
-    groups = {}
-    for gi, img_id in enumerate(mine):
-        print(f"Analyzing {img_id}...", flush=True)
+
+    def load_fn(img_id):
         try:
-            img = load_image_2d(paths[img_id], args.channel, args.time)
+            return load_image_2d(paths[img_id], args.channel, args.time)
         except (OSError, ValueError) as error:
             print(f"{FAIL}{error}", flush=True)
             sys.exit(1)
+
+    def width_fn(img_id, img):
+        # image_width_microns: the option / config key, else per image from the file's metadata (reference
+        # compute_branches.py:184-212: img.shape[-1] * PhysicalPixelSizes.X), else the reference's failure message
         width_um = config.get("image_width_microns")
         if width_um is None:
             px = helper.physical_pixel_sizes(paths[img_id]).X
@@ -183,18 +199,17 @@ def main(args=None):
                       "Exiting...", flush=True)
                 sys.exit(1)
             width_um = img.shape[-1] * px
-        groups.setdefault((img.shape, float(width_um), 8 * img.dtype.itemsize), []).append((ids.index(img_id), img))
-    for (shape, width_um, bits), items in groups.items():
-        batch = np.stack([im for _, im in items]).astype(np.uint16)
-        for cfg, suffix in grid:
-            rows = branches.analyze_batch(model.handle, batch, config, width_um, model.ds_ratio,
-                                          thresh=(cfg["thresh1"], cfg["thresh2"]), input_bits=bits)
-            um = lambda px: branches.pixels_to_microns(px, DOWNSAMPLE_WIDTH, width_um)
-            for (gidx, _), r in zip(items, rows):
-                results[suffix].append((gidx, r[1], um(r[2]), um(r[3])))
+        return width_um
+
+    def analyze_fn(batch, width_um, thresh, input_bits):
+        return branches.analyze_batch(model.handle, batch, config, width_um, model.ds_ratio, thresh=thresh, input_bits=input_bits)
+
+    grid = branches.threshold_grid(config)
+    gathered = branches.run_sharded(ids, load_fn, width_fn, analyze_fn, config, rank, ws,
+                                    log=lambda m: print(m, flush=True))
     created = set()
     for _, suffix in grid:
-        rows = distributed.gather_rows(results[suffix])
+        rows = gathered[suffix]
         if rank != 0:
             continue
         output_file = out_root / f"branching_analysis{suffix}.csv"

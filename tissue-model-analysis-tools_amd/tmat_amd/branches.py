@@ -73,3 +73,43 @@ def analyze_batch(handle: _lib.Handle, imgs: np.ndarray, config: dict, image_wid
     else:
         _lib.check(L.tmat_analyze_batch_dev(handle.raw, C.c_void_p(dev_ptr), *args), "tmat_analyze_batch_dev")
     return [(r.index, r.count, r.total_px, r.avg_px) for r in rows]
+
+
+def run_sharded(ids, load_fn, width_fn, analyze_fn, config: dict, rank: int = 0, world_size: int = 1, chunk: int = 64,
+                log=print):
+    """The per-run driver of scripts/compute_branches.py (reference :585-594 loops over the images one by one):
+    rank `rank` of `world_size` takes a contiguous block of `ids`, loads its images in bounded chunks of at most `chunk`
+    (images of equal shape, physical width and bit depth are analysed as one batch), and all ranks exchange their rows
+    with one all-gather per threshold configuration.
+
+    load_fn(img_id) -> uint8/uint16 (H, W) array; width_fn(img_id, img) -> image width in microns;
+    analyze_fn(batch uint16 (n, H, W), width_um, thresh=(t1, t2), input_bits=8|16) -> [(i, count, total_px, avg_px)].
+    Returns {file-name suffix: [(global index, count, total_um, avg_um)] sorted by index}, on every rank."""
+    from . import distributed
+    ids = list(ids)
+    grid = threshold_grid(config)
+    results = {suffix: [] for _, suffix in grid}
+    mine = distributed.shard_indices(len(ids), rank, world_size)
+
+    def flush(groups):
+        for (shape, width_um, bits), items in groups.items():
+            batch = np.stack([im for _, im in items]).astype(np.uint16)
+            for cfg, suffix in grid:
+                rows = analyze_fn(batch, width_um, thresh=(cfg["thresh1"], cfg["thresh2"]), input_bits=bits)
+                for (gidx, _), r in zip(items, rows):
+                    results[suffix].append((gidx, r[1], pixels_to_microns(r[2], DOWNSAMPLE_WIDTH, width_um),
+                                            pixels_to_microns(r[3], DOWNSAMPLE_WIDTH, width_um)))
+
+    groups, held = {}, 0
+    for gidx in mine:
+        img_id = ids[int(gidx)]
+        log(f"Analyzing {img_id}...")
+        img = load_fn(img_id)
+        width_um = width_fn(img_id, img)
+        groups.setdefault((img.shape, float(width_um), 8 * img.dtype.itemsize), []).append((int(gidx), img))
+        held += 1
+        if held >= chunk:           # bounded host / HBM footprint: the reference streams one image at a time
+            flush(groups)
+            groups, held = {}, 0
+    flush(groups)
+    return {suffix: distributed.gather_rows(results[suffix], n_total=len(ids)) for _, suffix in grid}

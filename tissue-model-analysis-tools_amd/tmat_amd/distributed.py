@@ -20,27 +20,42 @@ def shard_indices(n: int, rank: int, world_size: int) -> np.ndarray:
     return np.arange(lo, hi)
 
 
-def gather_rows(rows_local, device=None):
-    """rows_local: list of (index, count, total_px, avg_px).  Returns the rows of ALL ranks sorted by index
-    (on every rank).  Single process: returns the input sorted."""
+ROW_DTYPE = np.dtype([("index", "<i8"), ("count", "<i8"), ("total", "<f8"), ("avg", "<f8")])      # the 32-byte result row
+
+
+def host_threads_per_rank(world_size: int) -> int:
+    """host worker threads one rank may use for the thinning / DMT / MorseGraph stages: the cores this process may run
+    on, divided by the ranks of the node (every rank otherwise spawns hardware_concurrency workers)"""
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 8
+    return max(1, min(ncpu // max(1, world_size), 32))
+
+
+def gather_rows(rows_local, n_total=None, device=None):
+    """rows_local: list of (index, count, total_px, avg_px).  Returns the rows of ALL ranks sorted by index (on every
+    rank) with ONE fixed-size all-gather: every rank pads its shard to ceil(n_total / world) rows of 32 bytes (the
+    padding carries index -1).  `n_total` = number of rows over all ranks (the images of the run); when it is not
+    given, a contiguous block partition of at most len(rows_local) + 1 rows per rank is assumed (shard_indices).
+    Single process: returns the input sorted."""
     import torch
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return sorted(rows_local, key=lambda r: r[0])
     ws = dist.get_world_size()
+    cap = -(-int(n_total) // ws) if n_total is not None else len(rows_local) + 1
+    if len(rows_local) > cap:
+        raise ValueError(f"gather_rows: {len(rows_local)} local rows exceed the shard capacity {cap}")
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-    cnt = torch.tensor([len(rows_local)], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(cnt) for _ in range(ws)]
-    dist.all_gather(counts, cnt)
-    m = max(int(c.item()) for c in counts)
-    buf = torch.zeros((m, 4), dtype=torch.float64, device=dev)
-    if rows_local:
-        buf[: len(rows_local)] = torch.tensor([[float(r[0]), float(r[1]), r[2], r[3]] for r in rows_local], dtype=torch.float64)
-    allbuf = [torch.zeros_like(buf) for _ in range(ws)]
-    dist.all_gather(allbuf, buf)
-    out = []
-    for c, b in zip(counts, allbuf):
-        for r in b[: int(c.item())].cpu().tolist():
-            out.append((int(r[0]), int(r[1]), r[2], r[3]))
-    return sorted(out, key=lambda r: r[0])
+    mine = np.zeros(cap, ROW_DTYPE)
+    mine["index"] = -1
+    for k, r in enumerate(rows_local):
+        mine[k] = (int(r[0]), int(r[1]), float(r[2]), float(r[3]))
+    inp = torch.from_numpy(mine.view(np.uint8).reshape(cap * ROW_DTYPE.itemsize)).to(dev)
+    out = torch.empty(ws * cap * ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, inp)           # the one collective of the path (RCCL over xGMI on GPUs)
+    allrows = out.cpu().numpy().view(ROW_DTYPE)
+    allrows = allrows[allrows["index"] >= 0]
+    return sorted(((int(r["index"]), int(r["count"]), float(r["total"]), float(r["avg"])) for r in allrows), key=lambda r: r[0])

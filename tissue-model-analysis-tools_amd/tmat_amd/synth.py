@@ -28,6 +28,31 @@ MAGIC = b"TMATW001"
 
 
 # --------------------------------------------------------------------------------------
+# work accounting (what the GPU path executes on the matrix cores; bench.py's path-level roofline fraction)
+# --------------------------------------------------------------------------------------
+def mfma_flops_per_patch(filter_counts=None, patch: int = None) -> float:
+    """FLOPs per patch that the HIP path runs on MFMA (csrc/tmat_api.cpp schedule): pointwise and residual 1x1
+    convolutions (residuals of the up path hoisted below the upsampling), the 3x3 transposed convolutions, and the
+    sub-pixel form (16 instead of 36 tap-pairs... i.e. 4 taps per parity class) for those that read an upsampled tensor.
+    The stem, the depthwise taps and the final 64 -> 1 convolution run on the vector ALUs and are not counted."""
+    f = list(filter_counts or FILTER_COUNTS)
+    P = patch or PATCH_SIZE
+    fl = 0.0
+    H, cin = P // 2, f[0]
+    for cout in f[1:]:                       # down blocks
+        fl += 2.0 * H * H * cin * cout + 2.0 * H * H * cout * cout + 2.0 * (H // 2) ** 2 * cin * cout
+        H //= 2
+        cin = cout
+    Hs, up = H, 0
+    for cout in f[::-1]:                     # up blocks; Hs = stored resolution of the block input
+        taps1 = 16 if up else 9              # sub-pixel: 4 classes x 4 taps over the stored pixels
+        Hl = Hs << up
+        fl += 2.0 * Hs * Hs * taps1 * cin * cout + 2.0 * Hs * Hs * cin * cout + 2.0 * Hl * Hl * 9 * cout * cout
+        Hs, up, cin = Hl, 1, cout
+    return fl
+
+
+# --------------------------------------------------------------------------------------
 # images
 # --------------------------------------------------------------------------------------
 def synth_image(index: int, size: int = 1024, n_vessels: int = 40, scale: float = None) -> np.ndarray:
