@@ -64,8 +64,8 @@ def _axis_table(n_src: int, n_dst: int):
 
 def lanczos4_resize_u16(img: np.ndarray, out_hw, sat: int = 65535) -> np.ndarray:
     """u16 (H, W) -> u16 (h, w): separable 8-tap Lanczos4, replicate border, f32 accumulate
-    left-to-right (no FMA), horizontal then vertical, round-half-even + saturate (to `sat`: cv2 saturates to the
-    depth of its input, so an image that was uint8 before widening uses 255)."""
+    left-to-right (no FMA), horizontal then vertical, round-half-even + saturate: cv2's path for CV_16U
+    (HResizeLanczos4<ushort, float, float>, Cast<float, ushort>).  uint8 sources take lanczos4_resize_u8."""
     H, W = img.shape
     h, w = out_hw
     xi, xc = _axis_table(W, w)
@@ -78,6 +78,38 @@ def lanczos4_resize_u16(img: np.ndarray, out_hw, sat: int = 65535) -> np.ndarray
     for k in range(8):
         out = (out + tmp[yi[:, k], :] * yc[:, k, None]).astype(np.float32)
     return np.clip(np.rint(out), 0, sat).astype(np.uint16)
+
+
+def lanczos4_resize_u8(img: np.ndarray, out_hw) -> np.ndarray:
+    """uint8 sources.  cv2.resize does NOT run the float path on CV_8U: resize.cpp instantiates
+    HResizeLanczos4<uchar, int, short> / VResizeLanczos4<uchar, int, short, FixedPtCast<int, uchar, 22>>: the float
+    interpolateLanczos4 coefficients become 11-bit fixed point (saturate_cast<short>(c * 2048): round half to even; no
+    renormalisation of their sum), both passes accumulate in int32, and the result is (v + 2^21) >> 22 saturated to
+    0..255.  `img` holds 8-bit values (any integer dtype); returns uint16 for the common pipeline.
+    OpenCV is absent here: parity unpinned against cv2, pinned to hand-derived vectors (tests/test_oracle_morph.py)."""
+    img = np.asarray(img)
+    if img.max(initial=0) > 255:
+        raise ValueError("lanczos4_resize_u8: values above 255")
+    H, W = img.shape
+    h, w = out_hw
+    xi, xc = _axis_table(W, w)
+    yi, yc = _axis_table(H, h)
+    xa = np.rint(xc * np.float32(2048.0)).astype(np.int64)         # saturate_cast<short>: |c * 2048| < 32768 always
+    ya = np.rint(yc * np.float32(2048.0)).astype(np.int64)
+    src = img.astype(np.int64)
+    tmp = np.zeros((H, w), np.int64)
+    for k in range(8):
+        tmp += src[:, xi[:, k]] * xa[None, :, k]
+    out = np.zeros((h, w), np.int64)
+    for k in range(8):
+        out += tmp[yi[:, k], :] * ya[:, k, None]
+    assert np.abs(out).max(initial=0) < 2 ** 31                    # cv2 accumulates in int: no wrap possible for 8-bit data
+    return np.clip((out + (1 << 21)) >> 22, 0, 255).astype(np.uint16)
+
+
+def lanczos4_resize(img: np.ndarray, out_hw, input_bits: int = 16) -> np.ndarray:
+    """cv2.resize(INTER_LANCZOS4) by source depth: float path for uint16, fixed-point path for uint8"""
+    return lanczos4_resize_u8(img, out_hw) if input_bits == 8 else lanczos4_resize_u16(img, out_hw)
 
 
 def target_shape(shape, ratio: float):

@@ -29,7 +29,7 @@ def px_params(config: dict, field_width: int, image_width_microns: float):
 
 def segment(img_u16: np.ndarray, weights, ds_ratio=0.625, unet_kind="exact", patch=320, input_bits=16):
     tgt = morph.resized_shape(img_u16.shape, ds_ratio)       # cv2's dsize is (width, height): see morph.target_shape
-    small = morph.lanczos4_resize_u16(img_u16, tgt, sat=(1 << input_bits) - 1)
+    small = morph.lanczos4_resize(img_u16, tgt, input_bits)
     x = morph.rescale_intensity(small, (0, 1)).astype(np.float32)
     pf = unet.predict_exact(weights) if unet_kind == "exact" else unet.predict_torch(weights)
     return blend.predict_img_with_smooth_windowing(x, patch, 2, pf)

@@ -165,18 +165,27 @@ def test_images_that_need_more_patches_than_the_workspace(weights, images, oracl
         h.close()
 
 
-def test_eight_bit_sources_saturate_at_255(handle, weights):
-    """cv2.resize saturates its result to the depth of its input: for an image that was uint8 the Lanczos overshoot next
-    to saturated regions clips at 255, not at 65535 (tmat_set_input_depth / input_bits=8)"""
+def test_eight_bit_sources_take_the_fixed_point_path(handle, weights):
+    """cv2.resize runs uint8 images through its fixed-point Lanczos path (11-bit coefficients, int32 accumulation,
+    (v + 2^21) >> 22, saturation at 255) -- tmat_set_input_depth / input_bits=8; the float path is for uint16 only."""
     from oracle import morph, pipeline
-    from tmat_amd import branches, synth
+    from tmat_amd import _lib, branches, synth
     img16 = synth.synth_image(1, 512, n_vessels=12, scale=1.0)
     img8 = np.clip(img16.astype(np.float64) / 120.0, 0, 255).astype(np.uint8)      # large saturated areas
     assert (img8 == 255).mean() > 0.01
     wide = img8.astype(np.uint16)
-    s8 = morph.lanczos4_resize_u16(wide, (320, 320), sat=255)
+    s8 = morph.lanczos4_resize_u8(wide, (320, 320))
     s16 = morph.lanczos4_resize_u16(wide, (320, 320))
     assert s16.max() > 255 and s8.max() == 255                                   # the overshoot exists and is clipped
+    assert (s8.astype(int) != np.minimum(s16, 255).astype(int)).any()             # and the two arithmetic paths do differ
+    # the resized image itself, through the segment entry point: compare the probability maps bit for bit
+    L = _lib.lib()
+    pred = np.empty((1, 320, 320), np.float64)
+    _lib.check(L.tmat_set_input_depth(handle.raw, 8), "depth")
+    _lib.check(L.tmat_segment_batch(handle.raw, _lib.ptr(wide[None]), 1, 512, 512, 0.625, _lib.ptr(pred)), "segment")
+    _lib.check(L.tmat_set_input_depth(handle.raw, 16), "depth")
+    want = pipeline.segment(wide, weights, input_bits=8)
+    assert np.array_equal(pred[0].view(np.uint64), want.view(np.uint64))
     row8 = branches.analyze_batch(handle, wide[None], CFG, 500.0, input_bits=8)[0]
     assert row8[1:] == tuple(pipeline.analyze_image(wide, weights, CFG, 500.0, input_bits=8))
     row16 = branches.analyze_batch(handle, wide[None], CFG, 500.0)[0]             # and the default depth is restored per call
@@ -194,3 +203,25 @@ def test_nonsquare_segment_follows_cv2_dsize_order(handle, weights):
     _lib.check(_lib.lib().tmat_segment_batch(handle.raw, _lib.ptr(img[None]), 1, 256, 320, 0.625, _lib.ptr(pred)), "segment")
     want = pipeline.segment(img, weights)
     assert want.shape == (200, 160) and np.array_equal(pred[0].view(np.uint64), want.view(np.uint64))
+
+
+def test_malformed_weight_blobs_are_refused(weights):
+    """TMATW001 parsing: offsets / counts that would wrap, truncated tables and tensors whose shapes do not fit the layer
+    plan are refused with a message instead of being read out of bounds"""
+    import struct
+    from tmat_amd import _lib, synth
+    blob = bytearray(synth.pack_weights(weights))
+
+    def refuse(b, what):
+        with pytest.raises(Exception, match=what):
+            _lib.Handle(bytes(b), 0, 8).close()
+    refuse(blob[:90], "truncated")
+    refuse(blob[:100], "bad entry|truncated")
+    bad = bytearray(blob); struct.pack_into("<Q", bad, 16 + 76, 0xFFFFFFFFFFFFFFF0)        # count of entry 0: off + cnt * 4 wraps
+    refuse(bad, "bad entry")
+    bad = bytearray(blob); struct.pack_into("<Q", bad, 16 + 68, 0xFFFFFFFFFFFFFFFC)        # offset of entry 0 beyond the blob
+    refuse(bad, "bad entry")
+    w2 = dict(weights); w2["down0.bn1"] = w2["down0.bn1"][:, :64].copy()                  # BN block of the wrong width
+    refuse(synth.pack_weights(w2), "does not match|unexpected shape")
+    w3 = dict(weights); del w3["up2.res.b"]
+    refuse(synth.pack_weights(w3), "missing tensor")

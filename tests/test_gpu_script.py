@@ -99,3 +99,27 @@ def test_script_refuses_z_stacks(tmp_path):
         Image.fromarray(np.zeros((64, 64), np.uint16)).save(ind / f"well_z{z}.tif")
     r = run([str(ind), str(tmp_path / "o"), "--image-width-microns", "100"])
     assert r.returncode == 1 and "Z stacks" in r.stdout
+
+
+def test_script_visualizations_and_time_refusal(tmp_path, handle, weights):
+    """--visualizations writes the reference's four image dumps per image (compute_branches.py:315, 331, 347, 348); the
+    prediction picture is the 0..255 rescale of the GPU path's own probability map.  --time other than 0 is refused."""
+    from PIL import Image
+    from oracle import pipeline
+    from tmat_amd import synth
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir()
+    img = synth.synth_image(3, 512, n_vessels=12, scale=1.0)
+    np.save(ind / "v_0.npy", img)
+    r = run([str(ind), str(outd), "--image-width-microns", "500", "--visualizations"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    vdir = outd / "visualizations" / "v_0"
+    names = sorted(p.name for p in vdir.iterdir())
+    assert names == ["distance_transform.png", "original_image.png", "prediction.png", "segmentation_mask.png"]
+    pred = pipeline.segment(img, weights)
+    want = np.rint((pred - pred.min()) / (pred.max() - pred.min()) * 255.0).astype(np.uint8)
+    assert np.array_equal(np.array(Image.open(vdir / "prediction.png")), want)
+    seg = np.array(Image.open(vdir / "segmentation_mask.png"))
+    assert set(np.unique(seg)) <= {0, 255} and seg.shape == pred.shape
+    r = run([str(ind), str(tmp_path / "o2"), "--image-width-microns", "500", "--time", "2"])
+    assert r.returncode == 1 and "--time 2" in r.stdout

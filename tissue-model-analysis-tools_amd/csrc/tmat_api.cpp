@@ -46,10 +46,14 @@ static bool parse_blob(const void *blob, size_t nbytes, std::map<std::string, Te
         uint32_t ndim, d[4]; uint64_t off, cnt;
         memcpy(&ndim, p + pos + 48, 4); memcpy(d, p + pos + 52, 16);
         memcpy(&off, p + pos + 68, 8); memcpy(&cnt, p + pos + 76, 8);
-        if (ndim > 4 || off % 4 || off + cnt * 4 > nbytes) { set_error("weights: bad entry"); return false; }
+        // overflow-safe bounds: off inside the blob, cnt floats fit behind it (no off + cnt * 4 that could wrap)
+        if (ndim > 4 || off % 4 || off > nbytes || cnt > (nbytes - off) / 4) { set_error("weights: bad entry"); return false; }
         Tensor t; t.data = (const float *)(p + off); t.count = cnt;
-        size_t prod = 1;
-        for (uint32_t k = 0; k < ndim; k++) { t.shape.push_back((int)d[k]); prod *= d[k]; }
+        uint64_t prod = 1;
+        for (uint32_t k = 0; k < ndim; k++) {
+            if (d[k] == 0 || d[k] > (1u << 24) || prod > (1ull << 40)) { set_error("weights: bad dimension"); return false; }
+            t.shape.push_back((int)d[k]); prod *= d[k];
+        }
         if (prod != cnt) { set_error("weights: shape/count mismatch"); return false; }
         out[name] = t;
     }
@@ -126,6 +130,15 @@ static bool need(const std::map<std::string, Tensor> &m, const std::string &k, T
     t = it->second;
     return true;
 }
+// shape checks of what build_model indexes: a BatchNormalization block is (4, C) [gamma, beta, mean, var], a bias is (C)
+static bool bn_ok(const Tensor &bn, const Tensor &bias, int C)
+{
+    if (bn.shape.size() != 2 || bn.shape[0] != 4 || bn.shape[1] != C || (int)bias.count != C) {
+        set_error("weights: BatchNormalization / bias tensor does not match its convolution");
+        return false;
+    }
+    return true;
+}
 
 static bool build_model(Ctx *c, const std::map<std::string, Tensor> &m)
 {
@@ -134,6 +147,8 @@ static bool build_model(Ctx *c, const std::map<std::string, Tensor> &m)
     if (!need(m, "stem.w", w) || !need(m, "stem.b", b) || !need(m, "stem.bn", bn)) return false;
     if (w.shape.size() != 4 || w.shape[2] != 1) { set_error("weights: only channels=1 supported"); return false; }
     c->f0 = w.shape[3];
+    if (w.shape[0] != 3 || w.shape[1] != 3) { set_error("weights: stem must be 3x3"); return false; }
+    if (!bn_ok(bn, b, c->f0)) return false;
     fold_bn(bn, b, sc, sh);
     if (!upload(c, std::vector<float>(w.data, w.data + w.count), &c->stem_w) || !upload(c, sc, &c->stem_scale) ||
         !upload(c, sh, &c->stem_shift)) return false;
@@ -147,6 +162,11 @@ static bool build_model(Ctx *c, const std::map<std::string, Tensor> &m)
             std::string sp = p + (s ? ".sep2" : ".sep1");
             if (!need(m, sp + ".dw", dw) || !need(m, sp + ".pw", pw) || !need(m, sp + ".b", b) ||
                 !need(m, p + (s ? ".bn2" : ".bn1"), bn)) return false;
+            if (dw.shape.size() != 3 || pw.shape.size() != 2 || dw.count != (size_t)9 * pw.shape[0] || pw.shape[0] != (s ? d.cout : d.cin) ||
+                !bn_ok(bn, b, pw.shape[1])) {
+                set_error("weights: separable convolution tensors of " + sp + " have unexpected shapes");
+                return false;
+            }
             fold_bn(bn, b, sc, sh);
             {   // [9][C] -> [C/16][9][16]
                 const int C = (int)(dw.count / 9);
@@ -164,6 +184,7 @@ static bool build_model(Ctx *c, const std::map<std::string, Tensor> &m)
             d.cout = pw.shape[1];
         }
         if (!need(m, p + ".res.w", w) || !need(m, p + ".res.b", rb)) return false;
+        if (w.count != (size_t)d.cin * d.cout || (int)rb.count != d.cout) { set_error("weights: residual convolution of " + p + " has unexpected shape"); return false; }
         if (!upload(c, k_contiguous(w.data, 1, d.cin, d.cout), &d.res_w) ||
             !upload(c, std::vector<float>(rb.data, rb.data + rb.count), &d.res_b)) return false;
         c->down.push_back(d);
@@ -178,6 +199,7 @@ static bool build_model(Ctx *c, const std::map<std::string, Tensor> &m)
             std::string sp = p + (s ? ".ct2" : ".ct1");
             if (!need(m, sp + ".w", w) || !need(m, sp + ".b", b) || !need(m, p + (s ? ".bn2" : ".bn1"), bn)) return false;
             if (w.shape.size() != 4 || w.shape[0] != 3 || w.shape[1] != 3) { set_error("weights: ConvT must be 3x3"); return false; }
+            if (w.shape[3] != (s ? w.shape[2] : u.cin) || !bn_ok(bn, b, w.shape[2])) { set_error("weights: transposed convolution tensors of " + sp + " have unexpected shapes"); return false; }
             fold_bn(bn, b, sc, sh);
             const std::vector<float> w9 = convt_as_conv(w);
             const int I = w.shape[3], O = w.shape[2];
@@ -187,6 +209,7 @@ static bool build_model(Ctx *c, const std::map<std::string, Tensor> &m)
             u.cout = w.shape[2];
         }
         if (!need(m, p + ".res.w", w) || !need(m, p + ".res.b", rb)) return false;
+        if (w.count != (size_t)u.cin * u.cout || (int)rb.count != u.cout) { set_error("weights: residual convolution of " + p + " has unexpected shape"); return false; }
         if (!upload(c, k_contiguous(w.data, 1, u.cin, u.cout), &u.res_w) ||
             !upload(c, std::vector<float>(rb.data, rb.data + rb.count), &u.res_b)) return false;
         c->up.push_back(u);

@@ -145,6 +145,22 @@ __global__ __launch_bounds__(256) void zproj_reduce_kernel(const uint16_t *__res
         double s = 0.0;                                  // integers: exact in any order (np.mean, f64 accumulator)
         for (int z = 0; z < Z; z++) s += (double)st[(size_t)z * npx];
         out64[o] = s / (double)Z;
+    } else if (Z > ZMED_MAX) {                           // median of a deep stack: bitwise radix select, no slice limit
+        // k-th smallest (0-based) of the Z values: walk the 16 bits from the top; among the values that share the
+        // prefix chosen so far, count those with the current bit clear: the k-th lies among them iff k < count.
+        auto kth = [&](int k) {
+            unsigned prefix = 0;
+            for (int bit = 15; bit >= 0; bit--) {
+                int c0 = 0;
+                for (int z = 0; z < Z; z++) {
+                    const unsigned x = st[(size_t)z * npx];
+                    c0 += ((x >> (bit + 1)) == (prefix >> (bit + 1)) && !((x >> bit) & 1u)) ? 1 : 0;
+                }
+                if (k >= c0) { prefix |= 1u << bit; k -= c0; }
+            }
+            return prefix;
+        };
+        out64[o] = (Z & 1) ? (double)kth(Z / 2) : ((double)kth(Z / 2 - 1) + (double)kth(Z / 2)) / 2.0;
     } else {                                             // median (np.median: mean of the middle value(s))
         uint16_t v[ZMED_MAX];
         for (int z = 0; z < Z; z++) {                    // insertion sort
@@ -162,7 +178,6 @@ int zproj_dev(const uint16_t *stacks, int n, int Z, int H, int W, int method, vo
     if (method == TMAT_ZPROJ_FS) {
         hipLaunchKernelGGL(zproj_focus_kernel, dim3((W + ZT - 1) / ZT, (H + ZT - 1) / ZT, n), dim3(256), 0, s, stacks, Z, H, W, (uint16_t *)out);
     } else {
-        if (method == TMAT_ZPROJ_MED && Z > ZMED_MAX) { set_error("zproj: median supports at most 64 slices"); return -1; }
         const size_t npx = (size_t)H * W;
         hipLaunchKernelGGL(zproj_reduce_kernel, dim3((unsigned)((npx + 255) / 256), n), dim3(256), 0, s, stacks, Z, npx, method,
                            (uint16_t *)out, (double *)out);

@@ -9,7 +9,8 @@ scripts/compute_branches.py (2-D branch): same positional arguments, flags, conf
 
 Differences (documented in INTEGRATION.md): images are analysed in batches on the GPU (one process
 per GPU under torch.distributed.run; rows are gathered over RCCL and rank 0 writes the CSV);
-Z-stack inputs, --detect-well and the PNG visualisations are outside the accelerated path;
+Z-stack inputs and --detect-well are outside the accelerated path; the PNG image dumps are opt-in (--visualizations; the
+matplotlib barcode / tree plots are not reproduced);
 without --image-width-microns (or the config key) the width comes from OME / ImageJ TIFF metadata
 (tmat_amd/helper.py), as in the reference.
 """
@@ -49,6 +50,9 @@ def parse_branching_args(arg_defaults):
     p.add_argument("--remove-isolated-branches", action="store_true")
     p.add_argument("--graph-smoothing-window", type=float, default=None)
     p.add_argument("-c", "--config", type=str, default=arg_defaults["default_config_path"])
+    p.add_argument("--visualizations", action="store_true",
+                   help="also write visualizations/<image>/{original_image,prediction,segmentation_mask,distance_transform}.png "
+                        "(the reference always does; here it is opt-in: it re-runs the image through the staged entry points)")
     args = p.parse_args()
     if not args.remove_isolated_branches:
         args.remove_isolated_branches = None
@@ -204,8 +208,16 @@ def main(args=None):
     def analyze_fn(batch, width_um, thresh, input_bits):
         return branches.analyze_batch(model.handle, batch, config, width_um, model.ds_ratio, thresh=thresh, input_bits=input_bits)
 
+    vis = bool(getattr(args, "visualizations", False))
+
+    def load_and_keep(img_id):
+        img = load_fn(img_id)
+        if vis:
+            branches.save_visualizations(model.handle, img, out_root / "visualizations" / img_id, model.ds_ratio, 8 * img.dtype.itemsize)
+        return img
+
     grid = branches.threshold_grid(config)
-    gathered = branches.run_sharded(ids, load_fn, width_fn, analyze_fn, config, rank, ws,
+    gathered = branches.run_sharded(ids, load_and_keep, width_fn, analyze_fn, config, rank, ws,
                                     log=lambda m: print(m, flush=True))
     created = set()
     for _, suffix in grid:

@@ -148,8 +148,25 @@ def main(args=None):
 
     print("Loading and computing Z stacks...", flush=True)
     handle = zs.default_handle()
-    # project stacks of equal shape together (one launch per group)
-    groups = {}
+    # project stacks of equal shape together (one launch per group), in bounded chunks: at most CHUNK_BYTES of stacks are
+    # held in host memory / HBM at a time (the reference streams one stack at a time: compute_zproj.py:73-84)
+    CHUNK_BYTES = 2 << 30
+
+    def flush(groups):
+        for members in groups.values():
+            proj = handle.zproj(np.stack([m[2] for m in members]), args.method)
+            for (zs_id, zs_path, _), img in zip(members, proj):
+                out_ext = Path(np.atleast_1d(zs_path)[0]).suffix.lower()
+                if out_ext not in (".tif", ".tiff", ".png"):
+                    out_ext = ".tiff"
+                if img.dtype == np.float64 and out_ext == ".png":
+                    out_ext = ".tiff"
+                save_path = get_unique_output_filepath(os.path.join(out_root, f"{zs_id}_{args.method}{out_ext}"))
+                Path(save_path).parent.mkdir(parents=True, exist_ok=True)     # ids keep a folder part when stacks sit one per folder
+                save_projection(save_path, img)
+                print(f"Z projection saved to {save_path}", flush=True)
+
+    groups, held = {}, 0
     for zs_id, zs_path in zstack_paths.items():
         print(f"Processing {zs_id}...", flush=True)
         try:
@@ -158,18 +175,11 @@ def main(args=None):
             print(f"{FAIL}{error}", flush=True)
             sys.exit(1)
         groups.setdefault((st.shape, st.dtype.str), []).append((zs_id, zs_path, st))
-    for members in groups.values():
-        proj = handle.zproj(np.stack([m[2] for m in members]), args.method)
-        for (zs_id, zs_path, _), img in zip(members, proj):
-            out_ext = Path(np.atleast_1d(zs_path)[0]).suffix.lower()
-            if out_ext not in (".tif", ".tiff", ".png"):
-                out_ext = ".tiff"
-            if img.dtype == np.float64 and out_ext == ".png":
-                out_ext = ".tiff"
-            save_path = get_unique_output_filepath(os.path.join(out_root, f"{zs_id}_{args.method}{out_ext}"))
-            Path(save_path).parent.mkdir(parents=True, exist_ok=True)     # ids keep a folder part when stacks sit one per folder
-            save_projection(save_path, img)
-            print(f"Z projection saved to {save_path}", flush=True)
+        held += st.nbytes
+        if held >= CHUNK_BYTES:
+            flush(groups)
+            groups, held = {}, 0
+    flush(groups)
     print("... Projections saved.", flush=True)
     print(OK, flush=True)
 

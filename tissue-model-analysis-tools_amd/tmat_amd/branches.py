@@ -113,3 +113,48 @@ def run_sharded(ids, load_fn, width_fn, analyze_fn, config: dict, rank: int = 0,
             groups, held = {}, 0
     flush(groups)
     return {suffix: distributed.gather_rows(results[suffix], n_total=len(ids)) for _, suffix in grid}
+
+
+def save_visualizations(handle: _lib.Handle, img: np.ndarray, vis_dir, ds_ratio: float = 0.625, input_bits: int = 16):
+    """The four image dumps of the reference's 2-D branch (compute_branches.py:74-78 save_vis = rescale_intensity to
+    0..255 + cv2.imwrite; :315 original_image.png, :331 prediction.png, :347 segmentation_mask.png, :348
+    distance_transform.png) for one image, through the staged entry points of the same GPU path (segment ->
+    filter + EDT -> medial axis); the centre-line weighting of :341-344 is evaluated here with the scipy call the
+    reference makes.  The matplotlib barcode / tree plots (:431-450) are not reproduced.  Returns the written paths."""
+    import os
+    from pathlib import Path
+    from PIL import Image
+    from scipy.ndimage import distance_transform_edt
+
+    vis_dir = Path(vis_dir)
+    vis_dir.mkdir(parents=True, exist_ok=True)
+    img = np.ascontiguousarray(img, np.uint16)
+    H, W = img.shape
+    hh, ww = int(round(W * ds_ratio)), int(round(H * ds_ratio))            # cv2 reads dsize as (width, height)
+    L = _lib.lib()
+    pred = np.empty((1, hh, ww), np.float64)
+    _lib.check(L.tmat_set_input_depth(handle.raw, int(input_bits)), "tmat_set_input_depth")
+    _lib.check(L.tmat_segment_batch(handle.raw, _lib.ptr(img[None]), 1, H, W, float(ds_ratio), _lib.ptr(pred)), "tmat_segment_batch")
+    _lib.check(L.tmat_set_input_depth(handle.raw, 16), "tmat_set_input_depth")
+    filt, dist = handle.filter_edt(pred)
+    skel, _ = _lib.host_medial_axis(filt[0])
+    cdt = distance_transform_edt(np.logical_not(skel))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        weighted = pred[0] * (dist[0] / (dist[0] + cdt))
+    original = _lib.host_lanczos4_u16(img, (hh, ww))        # uint8 sources: float path, a 1-LSB-level difference in a picture
+
+    def save_vis(a, name):
+        a = np.asarray(a, np.float64)
+        lo, hi = np.nanmin(a), np.nanmax(a)
+        a = np.clip(a, lo, hi)
+        a = (a - lo) / (hi - lo) * 255.0 if hi != lo else np.clip(a, 0, 255)
+        file = vis_dir / name
+        stem, ext = os.path.splitext(file.name)
+        n = 1
+        while file.exists():                                # helper.get_unique_output_filepath
+            n += 1
+            file = vis_dir / f"{stem}-{n}{ext}"
+        Image.fromarray(np.rint(np.nan_to_num(a)).astype(np.uint8)).save(file)
+        return str(file)
+    return [save_vis(original, "original_image.png"), save_vis(pred[0], "prediction.png"),
+            save_vis(filt[0].astype(np.float64), "segmentation_mask.png"), save_vis(weighted, "distance_transform.png")]
