@@ -12,6 +12,7 @@
 // on host threads, one image per thread, while the GPU segments the next batch (tmat_analyze_*).
 #include "../../include/tmat.h"
 #include "tmat_internal.h"
+#include "postproc.h"
 
 #include <cmath>
 #include <cstring>
@@ -68,18 +69,12 @@ static inline int uf_find(int32_t *p, int v)
     return v;
 }
 
-int dmt_graph_host(const float *img, int R, int C, float delta1, float delta2, int32_t *verts, int cap_v, int32_t *edges,
-                   int cap_e, int *n_verts, int *n_edges)
+// lower-star order of the kept edges on the host (dmtgraph.py:71-93): sorted edge ids
+static void sorted_edges_host(const float *val, const Grid &gd, std::vector<int32_t> &out)
 {
-    *n_verts = 0; *n_edges = 0;
-    if (R < 1 || C < 1) { set_error("tmat_dmt_graph: empty image"); return TMAT_E_ARG; }
-    const Grid gd(R, C);
-    const int nV = R * C, nE = gd.n_edges(), nT = gd.n_tri();
-    std::vector<float> val(nV);
-    for (int i = 0; i < nV; i++) val[i] = -img[i];
+    const int nV = gd.R * gd.C, nE = gd.n_edges();
     std::vector<uint8_t> live(nV);
     for (int i = 0; i < nV; i++) live[i] = !(std::fabs((double)val[i]) <= 1e-8);
-
     // filtered edge list in canonical order with keys
     std::vector<int32_t> eid; eid.reserve(nE);
     std::vector<uint32_t> key; key.reserve(nE);
@@ -99,12 +94,31 @@ int dmt_graph_host(const float *img, int R, int C, float delta1, float delta2, i
         for (int i = 0; i < m; i++) tmp[cnt[(key[ord[i]] >> sh) & 255]++] = ord[i];
         ord.swap(tmp);
     }
+    out.resize(m);
+    for (int i = 0; i < m; i++) out[i] = eid[ord[i]];
+}
+
+// `sorted` / m: the kept edges in lower-star order when the device front end (csrc/dmt_kernels.hip) produced them; NULL =
+// filter and sort here
+int dmt_graph_host_sorted(const float *img, int R, int C, float delta1, float delta2, const int32_t *sorted, int m_in, int32_t *verts,
+                          int cap_v, int32_t *edges, int cap_e, int *n_verts, int *n_edges)
+{
+    *n_verts = 0; *n_edges = 0;
+    if (R < 1 || C < 1) { set_error("tmat_dmt_graph: empty image"); return TMAT_E_ARG; }
+    const Grid gd(R, C);
+    const int nV = R * C, nT = gd.n_tri();
+    std::vector<float> val(nV);
+    for (int i = 0; i < nV; i++) val[i] = -img[i];
+    std::vector<int32_t> own;
+    if (!sorted) { sorted_edges_host(val.data(), gd, own); sorted = own.data(); m_in = (int)own.size(); }
+    const int m = m_in;
+    const int32_t *se = sorted;
     // sorted edges: endpoints, key value, pairing state
     std::vector<int32_t> ea(m), eb(m);
     std::vector<float> ev(m), pers(m, std::numeric_limits<float>::infinity());
     std::vector<uint8_t> kind(m, 0);      // 0 unpaired, 1 vertex-edge, 2 edge-triangle
     for (int i = 0; i < m; i++) {
-        int a, b; gd.endpoints(eid[ord[i]], a, b);
+        int a, b; gd.endpoints(se[i], a, b);
         ea[i] = a; eb[i] = b; ev[i] = val[a] > val[b] ? val[a] : val[b];
     }
     // ---- ascending sweep: elder rule on vertices (younger = larger value, ties by larger index, dies) ----
@@ -136,7 +150,7 @@ int dmt_graph_host(const float *img, int R, int C, float delta1, float delta2, i
         for (int i = 0; i <= nT; i++) p[i] = i;
         for (int i = m - 1; i >= 0; i--) {
             if (kind[i]) continue;
-            int f, g; gd.faces(eid[ord[i]], f, g);
+            int f, g; gd.faces(se[i], f, g);
             int x = uf_find(p.data(), f), y = uf_find(p.data(), g);
             if (x == y) continue;
             const bool x_wins = tv[x] > tv[y] || (tv[x] == tv[y] && x > y);
@@ -211,14 +225,22 @@ int dmt_graph_host(const float *img, int R, int C, float delta1, float delta2, i
     return TMAT_OK;
 }
 
+int dmt_graph_host(const float *img, int R, int C, float delta1, float delta2, int32_t *verts, int cap_v, int32_t *edges,
+                   int cap_e, int *n_verts, int *n_edges)
+{
+    return dmt_graph_host_sorted(img, R, C, delta1, delta2, nullptr, 0, verts, cap_v, edges, cap_e, n_verts, n_edges);
+}
+
 }  // namespace tmat
 
-extern "C" int tmat_dmt_graph(tmat_handle, const float *img, int rows, int cols, float delta1, float delta2, int32_t *verts,
+extern "C" int tmat_dmt_graph(tmat_handle hd, const float *img, int rows, int cols, float delta1, float delta2, int32_t *verts,
                               int cap_v, int32_t *edges, int cap_e, int *n_verts, int *n_edges)
 {
     if (!img || !verts || !edges || !n_verts || !n_edges || cap_v < 0 || cap_e < 0) {
         tmat::set_error("tmat_dmt_graph: bad argument");
         return TMAT_E_ARG;
     }
-    return tmat::dmt_graph_host(img, rows, cols, delta1, delta2, verts, cap_v, edges, cap_e, n_verts, n_edges);
+    if (!hd || rows < 2 || cols < 2)      // no handle: host-only execution (key build and sort included)
+        return tmat::dmt_graph_host(img, rows, cols, delta1, delta2, verts, cap_v, edges, cap_e, n_verts, n_edges);
+    return tmat::dmt_graph_device_front(hd, img, rows, cols, delta1, delta2, verts, cap_v, edges, cap_e, n_verts, n_edges);
 }

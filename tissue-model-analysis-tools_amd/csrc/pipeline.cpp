@@ -59,6 +59,16 @@ static int ensure_pass_buffers(Ctx *c, int K, int H, int W, int h, int w, int fh
         TMAT_HIP(hipMalloc((void **)&b.f255[i], (size_t)K * fh * fw * sizeof(float)));
         TMAT_HIP(hipHostMalloc((void **)&b.f255_host[i], (size_t)K * fh * fw * sizeof(float), hipHostMallocDefault));
     }
+    if (fh >= 2 && fw >= 2) {
+        const size_t nE = dmt_edge_count(fh, fw);
+        TMAT_HIP(hipMalloc(&b.dmt_ws, dmt_workspace_bytes(K, fh, fw)));
+        for (int i = 0; i < 2; i++) {
+            TMAT_HIP(hipMalloc((void **)&b.dmt_ids[i], (size_t)K * nE * sizeof(int32_t)));
+            TMAT_HIP(hipHostMalloc((void **)&b.dmt_ids_host[i], (size_t)K * nE * sizeof(int32_t), hipHostMallocDefault));
+            TMAT_HIP(hipMalloc((void **)&b.dmt_m[i], (size_t)K * sizeof(int)));
+            TMAT_HIP(hipHostMalloc((void **)&b.dmt_m_host[i], (size_t)K * sizeof(int), hipHostMallocDefault));
+        }
+    }
     b.fh = fh; b.fw = fw;
     for (int i = 0; i < 2; i++) {
         TMAT_HIP(hipMalloc((void **)&b.pred[i], (size_t)K * h * w * sizeof(double)));
@@ -189,6 +199,14 @@ static void run_pass_host(Ctx *c, int slot, int k, const GraphParams gp, tmat_ro
     bool ok = hipMemcpyAsync(b.skel[slot], b.skel_host[slot], k * per, hipMemcpyHostToDevice, s) == hipSuccess;
     ok = ok && finish_dev(b.pred[slot], b.dist[slot], b.skel[slot], k, h, w, gp.fh, gp.fw, b.finish_ws, b.field[slot], b.f255[slot], s) == 0;
     ok = ok && hipMemcpyAsync(b.f255_host[slot], b.f255[slot], k * fper * sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess;
+    // DMT front end on the device: edge keys + lower-star sort from the field in HBM; the sorted edge ids come back
+    const bool dmt_dev = c->dmt_device && b.dmt_ws && gp.fh >= 2 && gp.fw >= 2;
+    const size_t nE = dmt_dev ? dmt_edge_count(gp.fh, gp.fw) : 0;
+    if (dmt_dev) {
+        ok = ok && dmt_sorted_edges_dev(b.f255[slot], k, gp.fh, gp.fw, b.dmt_ws, b.dmt_ids[slot], b.dmt_m[slot], s) == 0;
+        ok = ok && hipMemcpyAsync(b.dmt_ids_host[slot], b.dmt_ids[slot], k * nE * sizeof(int32_t), hipMemcpyDeviceToHost, s) == hipSuccess;
+        ok = ok && hipMemcpyAsync(b.dmt_m_host[slot], b.dmt_m[slot], k * sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess;
+    }
     ok = ok && hipStreamSynchronize(s) == hipSuccess;
     if (!ok) { job->rc = TMAT_E_HIP; return; }
     const double t2 = now_s();
@@ -196,7 +214,8 @@ static void run_pass_host(Ctx *c, int slot, int k, const GraphParams gp, tmat_ro
         const int cap_v = (int)fper + 4, cap_e = 3 * (int)fper + 4;
         std::vector<int32_t> V((size_t)cap_v * 2), E((size_t)cap_e * 2);
         int nv = 0, ne = 0;
-        int rc = dmt_graph_host(b.f255_host[slot] + i * fper, gp.fh, gp.fw, gp.t1, gp.t2, V.data(), cap_v, E.data(), cap_e, &nv, &ne);
+        int rc = dmt_graph_host_sorted(b.f255_host[slot] + i * fper, gp.fh, gp.fw, gp.t1, gp.t2, dmt_dev ? b.dmt_ids_host[slot] + i * nE : nullptr,
+                                       dmt_dev ? b.dmt_m_host[slot][i] : 0, V.data(), cap_v, E.data(), cap_e, &nv, &ne);
         if (!rc)
             rc = tmat_morse_stats(V.data(), nv, E.data(), ne, gp.fh, gp.fw, gp.smooth, gp.min_len, gp.max_len, gp.remove_isolated, nullptr,
                                   &rows[i].count, &rows[i].total_px, &rows[i].avg_px, nullptr, 0);
@@ -252,6 +271,28 @@ static int analyze_dev(Ctx *c, const uint16_t *imgs_dev, int n, int H, int W, do
     hipStreamSynchronize(c->stream2);
     hipStreamSynchronize(c->stream);
     return rc;
+}
+
+// tmat_dmt_graph with a handle: key build + sort on the handle's device, sweeps + collect on the host
+int dmt_graph_device_front(void *handle, const float *img, int R, int C, float delta1, float delta2, int32_t *verts, int cap_v,
+                           int32_t *edges, int cap_e, int *n_verts, int *n_edges)
+{
+    Ctx *c = (Ctx *)handle;
+    TMAT_HIP(hipSetDevice(c->device));
+    const size_t nE = dmt_edge_count(R, C), npx = (size_t)R * C;
+    float *df = nullptr; void *ws = nullptr; int32_t *ids = nullptr; int *m = nullptr;
+    std::vector<int32_t> ids_host(nE);
+    int m_host = 0, rc = TMAT_OK;
+    if (!hip_ok(hipMalloc((void **)&df, npx * sizeof(float)), "hipMalloc") || !hip_ok(hipMalloc(&ws, dmt_workspace_bytes(1, R, C)), "hipMalloc") ||
+        !hip_ok(hipMalloc((void **)&ids, nE * sizeof(int32_t)), "hipMalloc") || !hip_ok(hipMalloc((void **)&m, sizeof(int)), "hipMalloc")) rc = TMAT_E_HIP;
+    if (!rc && !hip_ok(hipMemcpyAsync(df, img, npx * sizeof(float), hipMemcpyHostToDevice, c->stream), "H2D")) rc = TMAT_E_HIP;
+    if (!rc && dmt_sorted_edges_dev(df, 1, R, C, ws, ids, m, c->stream)) { set_error("tmat_dmt_graph: device front end failed"); rc = TMAT_E_HIP; }
+    if (!rc && (!hip_ok(hipMemcpyAsync(ids_host.data(), ids, nE * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream), "D2H") ||
+                !hip_ok(hipMemcpyAsync(&m_host, m, sizeof(int), hipMemcpyDeviceToHost, c->stream), "D2H") ||
+                !hip_ok(hipStreamSynchronize(c->stream), "sync"))) rc = TMAT_E_HIP;
+    hipFree(df); hipFree(ws); hipFree(ids); hipFree(m);
+    if (rc) return rc;
+    return dmt_graph_host_sorted(img, R, C, delta1, delta2, ids_host.data(), m_host, verts, cap_v, edges, cap_e, n_verts, n_edges);
 }
 
 }  // namespace tmat

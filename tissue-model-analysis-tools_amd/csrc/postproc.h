@@ -21,4 +21,9 @@ void resize_aa(const double *img, int H, int W, int oh, int ow, float *out);
 void postprocess_image(const double *pred, int H, int W, int oh, int ow, float *field);
 int dmt_graph_host(const float *img, int R, int C, float delta1, float delta2, int32_t *verts, int cap_v, int32_t *edges,
                    int cap_e, int *n_verts, int *n_edges);
+int dmt_graph_host_sorted(const float *img, int R, int C, float delta1, float delta2, const int32_t *sorted, int m, int32_t *verts,
+                          int cap_v, int32_t *edges, int cap_e, int *n_verts, int *n_edges);
+// with a handle: key build + lower-star sort on its device (csrc/dmt_kernels.hip), sweeps and collect on the host (pipeline.cpp)
+int dmt_graph_device_front(void *handle, const float *img, int R, int C, float delta1, float delta2, int32_t *verts, int cap_v,
+                           int32_t *edges, int cap_e, int *n_verts, int *n_edges);
 }  // namespace tmat

@@ -48,6 +48,12 @@ struct PassBuf {
     uint8_t *skel_host[2] = {nullptr, nullptr};
     float *field[2] = {nullptr, nullptr}, *f255[2] = {nullptr, nullptr};
     float *f255_host[2] = {nullptr, nullptr};
+    // DMT front end (dmt_kernels.hip): lower-star sorted edge ids of every image of the pass, counts of kept edges
+    void *dmt_ws = nullptr;
+    int32_t *dmt_ids[2] = {nullptr, nullptr};
+    int32_t *dmt_ids_host[2] = {nullptr, nullptr};
+    int *dmt_m[2] = {nullptr, nullptr};
+    int *dmt_m_host[2] = {nullptr, nullptr};
     hipEvent_t done[2] = {nullptr, nullptr};
 };
 
@@ -81,7 +87,7 @@ struct Ctx {
         PassBuf &b = pass;
         void *dev[] = {b.xi, b.yi, b.xc, b.yc, b.tmp, b.x, b.small, b.mn, b.mx, b.pred[0], b.pred[1], b.morph_ws,
                        b.filt[0], b.filt[1], b.dist[0], b.dist[1], b.finish_ws, b.skel[0], b.skel[1], b.field[0], b.field[1],
-                       b.f255[0], b.f255[1]};
+                       b.f255[0], b.f255[1], b.dmt_ws, b.dmt_ids[0], b.dmt_ids[1], b.dmt_m[0], b.dmt_m[1]};
         for (void *p : dev) if (p) hipFree(p);
         for (int i = 0; i < 2; i++) {
             if (b.pred_host[i]) hipHostFree(b.pred_host[i]);
@@ -90,10 +96,13 @@ struct Ctx {
             if (b.conv_host[i]) hipHostFree(b.conv_host[i]);
             if (b.skel_host[i]) hipHostFree(b.skel_host[i]);
             if (b.f255_host[i]) hipHostFree(b.f255_host[i]);
+            if (b.dmt_ids_host[i]) hipHostFree(b.dmt_ids_host[i]);
+            if (b.dmt_m_host[i]) hipHostFree(b.dmt_m_host[i]);
             if (b.done[i]) hipEventDestroy(b.done[i]);
         }
         pass = PassBuf();
     }
+    bool dmt_device = true;                                  // DMT key build + lower-star sort on the device (TMAT_DMT_DEVICE=0: host)
     bool fused_sep = true;                                   // fused depthwise->pointwise kernel where the level allows (TMAT_FUSED_SEP=0: off)
     // profiling of the dominant kernel family
     bool prof_on = false;

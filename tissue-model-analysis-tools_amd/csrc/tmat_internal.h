@@ -54,4 +54,9 @@ void launch_minmax_f32(const float *x, int n, size_t per, float *mn, float *mx, 
 void launch_extract_tiles(const float *x, const float *padval, int n, const TileGeom &g, float *patches, hipStream_t s);
 void launch_blend(const float *pred_patches, const double *win1d, int n, const TileGeom &g, double *out, hipStream_t s);
 
+// ---- DMT front end on the device (dmt_kernels.hip) -------------------------------------------------
+inline size_t dmt_edge_count(int R, int C) { return (size_t)(R - 1) * C + (size_t)R * (C - 1) + (size_t)(R - 1) * (C - 1); }
+size_t dmt_workspace_bytes(int n, int R, int C);
+int dmt_sorted_edges_dev(const float *field, int n, int R, int C, void *ws, int32_t *ids, int *m, hipStream_t s);
+
 }  // namespace tmat
