@@ -85,8 +85,8 @@ int tmat_segment_batch(tmat_handle h, const uint16_t *imgs, int n, int H, int W,
  * (transforms.py:306-361) -> medial_axis + EDT centre-line weighting -> skimage resize to
  * img_dsamp_res = (out_h, out_w) (compute_branches.py:218-222: round(orig_shape * 384 / orig_width)),
  * order 1, anti-aliased -> f32.   pred: (n, h, w) f64; field: (n, out_h, out_w) f32.
- * Runs on the handle's device with the same split as the batch pipeline: GPU (threshold, filter, EDT) -> host
- * (ordered medial-axis thinning, sequential by construction) -> GPU (EDT of the skeleton, weighting, resize).
+ * Runs on the handle's device like the batch pipeline: threshold, filter, EDT, ordered medial-axis thinning (only its
+ * tie-break permutation is made on the host), EDT of the skeleton, weighting, resize.
  * A handle from tmat_create_plain is enough.
  */
 int tmat_postprocess_batch(tmat_handle h, const double *pred, int n, int hh, int ww, int out_h, int out_w, float *field);
@@ -106,6 +106,17 @@ int tmat_filter_edt_batch(tmat_handle h, const double *pred, int n, int hh, int 
  */
 int tmat_filter_mask_batch(tmat_handle h, const uint8_t *mask, int n, int hh, int ww, int use_median, int remove_isolated,
                            uint8_t *filtered);
+
+/*
+ * skimage.morphology.medial_axis(mask, return_distance=True) (reference call compute_branches.py:340; scikit-image
+ * 0.18.3 semantics with the RandomState(0) tie-break) for a batch, on the device: exact EDT (morph_kernels.hip), then the
+ * ordered thinning (thin_kernels.hip: sort keys from distance / corner score / tie-break, stable radix sort, one wave
+ * per image walking the order with the mask as an LDS bitmap).  Only the tie-break permutation (a Mersenne-Twister
+ * shuffle that depends on the foreground COUNT alone) is produced on the host.  mask, skel (n, h, w) u8; dist (n, h, w)
+ * f64.  Images whose bitmaps do not fit LDS (beyond about 1400 x 1400) are refused here; the pipeline runs those
+ * through the host implementation (tmat_host_medial_axis).  A handle from tmat_create_plain is enough.
+ */
+int tmat_medial_axis_batch(tmat_handle h, const uint8_t *mask, int n, int hh, int ww, uint8_t *skel, double *dist);
 
 /*
  * The GPU stages after the medial-axis thinning (csrc/finish_kernels.hip): centerline_dt = EDT(~skel),

@@ -89,3 +89,52 @@ def test_filter_branch_seg_mask_mirror_options(use_median, remove_isolated):
         want = morph.filter_branch_seg_mask(m, use_median, remove_isolated)
         assert np.array_equal(got[i], want), i
     assert np.array_equal(transforms.filter_branch_seg_mask(masks[0], fp, remove_isolated), got[0])
+
+
+@pytest.mark.parametrize("name", ["d5", "m1", "blobs", "noise", "small", "empty", "full"])
+def test_device_medial_axis_matches_reference_goldens(handle, name):
+    """tmat_medial_axis_batch (EDT + key build + radix sort + ordered thinning, all on the device; only the RandomState(0)
+    permutation comes from the host) against skimage 0.18.3's medial_axis run on the reference's filtered masks
+    (tools/make_goldens.py filter): skeleton exact, distance map exact."""
+    import hashlib
+    filt = unpack(name, "filtered")
+    skel, dist = handle.medial_axis(filt[None])
+    assert np.array_equal(skel[0], unpack(name, "ma_skel"))
+    sha = np.frombuffer(hashlib.sha256(np.ascontiguousarray(dist[0]).tobytes()).digest(), np.uint8)
+    assert np.array_equal(sha, G[name + "_ma_dist_sha"])
+
+
+def test_device_medial_axis_batch_and_adversarial_order(handle):
+    """a batch of different images per launch, including masks where almost every pixel of the visiting order touches
+    its predecessor (thin diagonal lines, a checker of 2 x 2 blocks): the claim / cut logic of the thinning kernel then
+    advances a few lanes at a time and must still reproduce the sequential result"""
+    from oracle import morph
+    rs = np.random.RandomState(5)
+    H, W = 120, 150
+    yy, xx = np.mgrid[:H, :W]
+    masks = [ndi.gaussian_filter(rs.normal(size=(H, W)), 3) > 0.0,
+             (np.abs(yy - xx) % 7 < 2),                          # bundles of 2-px diagonals
+             ((yy // 2 + xx // 2) % 2 == 0),                     # 2 x 2 checker: every pixel has equal distance 1
+             np.ones((H, W), bool),
+             np.zeros((H, W), bool),
+             rs.uniform(size=(H, W)) > 0.3]
+    skel, dist = handle.medial_axis(np.stack(masks))
+    for i, m in enumerate(masks):
+        osk, odist = morph.medial_axis(m)
+        assert np.array_equal(dist[i], odist), i
+        assert np.array_equal(skel[i], osk), i
+
+
+def test_device_medial_axis_deep_blobs_repeatable(handle):
+    """large blobs at the pipeline's size: the dependency DAG is hundreds of levels deep, so the wavefront needs many
+    launches and tile halos matter (a workgroup must never finish a pixel whose predecessor its neighbour cannot finish
+    in the same launch).  Three runs of a batch of 8, each compared with the host implementation."""
+    from tmat_amd import _lib
+    rs = np.random.RandomState(1)
+    masks = np.stack([ndi.gaussian_filter(rs.normal(size=(640, 640)), s) > t
+                      for s, t in ((8, 0.0), (5, 0.01), (12, -0.005), (3, 0.02), (20, 0.0), (6, 0.0), (9, 0.01), (4, -0.01))])
+    ref = [_lib.host_medial_axis(m)[0] for m in masks]
+    for rep in range(3):
+        sk, _ = handle.medial_axis(masks)
+        for i in range(len(masks)):
+            assert np.array_equal(sk[i], ref[i]), (rep, i, int((sk[i] != ref[i]).sum()))

@@ -7,14 +7,13 @@
 //   dmt_keys_kernel : one thread per edge id e of the canonical enumeration (vertical, horizontal, anti-diagonal; the
 //                     order of dmtgraph.py:create_edges): key = order-preserving uint32 image of max(val[a], val[b]), or
 //                     0xFFFFFFFF for a dropped edge (sorts behind every live key); wave-aggregated count of live edges.
-//   dmt_sort_kernel : stable LSD radix sort (4 passes of 8 bits) of (key, e) pairs, one 1024-thread workgroup per image.
-//                     Stability IS the reference's tie-break (position in the filtered list = canonical order).  Per pass:
-//                     LDS histogram, wave scan, then chunks of 1024 pairs in order: every lane finds the lanes of its
-//                     wave that hold the same digit with 8 ballots (peer mask), its rank among them is a popcount below
-//                     its lane, per-wave digit counts are prefixed across the 16 waves in LDS.  HBM-bound in principle
+//   dmt_sort_kernel : stable LSD radix sort (4 passes of 8 bits) of (key, e) pairs, one 1024-thread workgroup per image
+//                     (block_radix_sort.h).  Stability IS the reference's tie-break (position in the filtered list =
+//                     canonical order).  HBM-bound in principle
 //                     (16 B per pair and pass); with one workgroup per image it is latency-bound (~0.3 ms per pass) and
 //                     runs on the finish stream under the UNet of the next pass.
 #include "tmat_internal.h"
+#include "block_radix_sort.h"
 
 namespace tmat {
 
@@ -48,75 +47,11 @@ __global__ __launch_bounds__(256) void dmt_keys_kernel(const float *__restrict__
     if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&m_out[img], __popcll(bal));
 }
 
-constexpr int DS_T = 1024, DS_W = DS_T / 64;
-__global__ __launch_bounds__(DS_T) void dmt_sort_kernel(uint32_t *__restrict__ k0, int32_t *__restrict__ v0, uint32_t *__restrict__ k1,
-                                                        int32_t *__restrict__ v1, int n)
+__global__ __launch_bounds__(BRS_T) void dmt_sort_kernel(uint32_t *__restrict__ k0, int32_t *__restrict__ v0, uint32_t *__restrict__ k1,
+                                                         int32_t *__restrict__ v1, int n)
 {
-    __shared__ unsigned hist[256];           // digit counts of the pass, then the running output base of every digit
-    __shared__ unsigned wcnt[DS_W][256];     // per-wave digit counts of a chunk, then their exclusive prefix over the waves
-    __shared__ unsigned tot[256];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const size_t off = (size_t)blockIdx.x * n;
-    uint32_t *kin = k0 + off, *kout = k1 + off;
-    int32_t *vin = v0 + off, *vout = v1 + off;
-    for (int pass = 0; pass < 4; pass++) {
-        const int sh = 8 * pass;
-        if (t < 256) hist[t] = 0;
-        __syncthreads();
-        for (int i = t; i < n; i += DS_T) atomicAdd(&hist[(kin[i] >> sh) & 255], 1u);
-        __syncthreads();
-        if (wave == 0) {                     // exclusive scan of the 256 counts: 4 per lane + a wave scan
-            unsigned c[4], s = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) { c[j] = hist[lane * 4 + j]; s += c[j]; }
-            unsigned incl = s;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const unsigned u = __shfl_up(incl, o); if (lane >= o) incl += u; }
-            unsigned run = incl - s;
-#pragma unroll
-            for (int j = 0; j < 4; j++) { hist[lane * 4 + j] = run; run += c[j]; }
-        }
-        __syncthreads();
-        for (int c0 = 0; c0 < n; c0 += DS_T) {
-            for (int j = t; j < DS_W * 256; j += DS_T) (&wcnt[0][0])[j] = 0;
-            __syncthreads();
-            const int i = c0 + t;
-            const bool valid = i < n;
-            const uint32_t key = valid ? kin[i] : 0u;
-            const int32_t val = valid ? vin[i] : 0;
-            const unsigned d = (key >> sh) & 255;
-            unsigned long long peers = __ballot(valid);
-#pragma unroll
-            for (int b = 0; b < 8; b++) {
-                const bool bit = (d >> b) & 1;
-                const unsigned long long bal = __ballot(bit);
-                peers &= bit ? bal : ~bal;
-            }
-            const unsigned rank = __popcll(peers & ((1ull << lane) - 1ull));
-            if (valid && rank == 0) wcnt[wave][d] = __popcll(peers);
-            __syncthreads();
-            if (t < 256) {                   // exclusive prefix over the waves, per digit
-                unsigned run = 0;
-#pragma unroll
-                for (int w = 0; w < DS_W; w++) { const unsigned c = wcnt[w][t]; wcnt[w][t] = run; run += c; }
-                tot[t] = run;
-            }
-            __syncthreads();
-            if (valid) {
-                const unsigned pos = hist[d] + wcnt[wave][d] + rank;
-                kout[pos] = key;
-                vout[pos] = val;
-            }
-            __syncthreads();
-            if (t < 256) hist[t] += tot[t];
-        }
-        __syncthreads();
-        // make this pass's scattered stores visible to the reads of the next one (same workgroup, through L2)
-        __threadfence();
-        __syncthreads();
-        uint32_t *tk = kin; kin = kout; kout = tk;
-        int32_t *tv = vin; vin = vout; vout = tv;
-    }
+    block_radix_sort<uint32_t, int32_t, 4>(k0 + off, v0 + off, k1 + off, v1 + off, n);
 }
 
 size_t dmt_workspace_bytes(int n, int R, int C)
@@ -136,7 +71,7 @@ int dmt_sorted_edges_dev(const float *field, int n, int R, int C, void *ws, int3
     int32_t *v1 = (int32_t *)(k1 + (size_t)n * nE);
     if (hipMemsetAsync(m, 0, n * sizeof(int), s) != hipSuccess) return -2;
     hipLaunchKernelGGL(dmt_keys_kernel, dim3((nE + 255) / 256, n), dim3(256), 0, s, field, R, C, nE, k0, ids, m);
-    hipLaunchKernelGGL(dmt_sort_kernel, dim3(n), dim3(DS_T), 0, s, k0, ids, k1, v1, nE);     // 4 passes: the result is back in (k0, ids)
+    hipLaunchKernelGGL(dmt_sort_kernel, dim3(n), dim3(BRS_T), 0, s, k0, ids, k1, v1, nE);     // 4 passes: the result is back in (k0, ids)
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -59,6 +59,15 @@ static int ensure_pass_buffers(Ctx *c, int K, int H, int W, int h, int w, int fh
         TMAT_HIP(hipMalloc((void **)&b.f255[i], (size_t)K * fh * fw * sizeof(float)));
         TMAT_HIP(hipHostMalloc((void **)&b.f255_host[i], (size_t)K * fh * fw * sizeof(float), hipHostMallocDefault));
     }
+    if (thin_dev_supported(h, w)) {
+        TMAT_HIP(hipMalloc(&b.thin_ws, thin_workspace_bytes(K, h, w)));
+        TMAT_HIP(hipMalloc((void **)&b.tie, (size_t)K * h * w * sizeof(uint32_t)));
+        for (int i = 0; i < 2; i++) {
+            TMAT_HIP(hipMalloc((void **)&b.nfg[i], (size_t)K * sizeof(int)));
+            TMAT_HIP(hipHostMalloc((void **)&b.nfg_host[i], (size_t)K * sizeof(int), hipHostMallocDefault));
+            TMAT_HIP(hipHostMalloc((void **)&b.tie_host[i], (size_t)K * h * w * sizeof(uint32_t), hipHostMallocDefault));
+        }
+    }
     if (fh >= 2 && fw >= 2) {
         const size_t nE = dmt_edge_count(fh, fw);
         TMAT_HIP(hipMalloc(&b.dmt_ws, dmt_workspace_bytes(K, fh, fw)));
@@ -83,6 +92,18 @@ static int ensure_pass_buffers(Ctx *c, int K, int H, int W, int h, int w, int fh
     b.K = K; b.H = H; b.W = W; b.h = h; b.w = w;
     return TMAT_OK;
 }
+
+// the decision table of the ordered thinning, uploaded once per handle
+static int ensure_ma_table(Ctx *c)
+{
+    if (c->ma_table) return TMAT_OK;
+    uint32_t bits[16];
+    medial_table_bits(bits);
+    TMAT_HIP(hipMalloc((void **)&c->ma_table, sizeof(bits)));
+    TMAT_HIP(hipMemcpy(c->ma_table, bits, sizeof(bits), hipMemcpyHostToDevice));
+    return TMAT_OK;
+}
+static bool thin_on_device(const Ctx *c) { return c->thin_device && c->pass.thin_ws != nullptr; }
 
 // GPU part of one pass: imgs_dev (k, H, W) u16 -> pred (k, h, w) f64 in b.pred[slot], copied to pinned host
 static int enqueue_segment(Ctx *c, const uint16_t *imgs_dev, int k, int slot)
@@ -139,8 +160,14 @@ static int enqueue_back(Ctx *c, int k, int slot, const TileGeom &g)
     rc = filter_edt_dev(b.pred[slot], k, b.h, b.w, 1, b.morph_ws, b.filt[slot], b.dist[slot], s);
     if (rc) return TMAT_E_HIP;
     const size_t npx = (size_t)k * b.h * b.w;
-    TMAT_HIP(hipMemcpyAsync(b.filt_host[slot], b.filt[slot], npx, hipMemcpyDeviceToHost, s));
-    TMAT_HIP(hipMemcpyAsync(b.dist_host[slot], b.dist[slot], npx * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (thin_on_device(c)) {
+        // the ordered thinning runs on the device too: the host only needs the foreground counts (for the permutations)
+        if (thin_count_dev(b.filt[slot], k, b.h, b.w, b.nfg[slot], s)) return TMAT_E_HIP;
+        TMAT_HIP(hipMemcpyAsync(b.nfg_host[slot], b.nfg[slot], k * sizeof(int), hipMemcpyDeviceToHost, s));
+    } else {
+        TMAT_HIP(hipMemcpyAsync(b.filt_host[slot], b.filt[slot], npx, hipMemcpyDeviceToHost, s));
+        TMAT_HIP(hipMemcpyAsync(b.dist_host[slot], b.dist[slot], npx * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
     TMAT_HIP(hipMemcpyAsync(b.conv_host[slot], morph_done_flags(b.morph_ws, k, b.h, b.w), k * sizeof(int), hipMemcpyDeviceToHost, s));
     TMAT_HIP(hipEventRecord(b.done[slot], s));
     return TMAT_OK;
@@ -192,11 +219,24 @@ static void run_pass_host(Ctx *c, int slot, int k, const GraphParams gp, tmat_ro
     const int h = b.h, w = b.w;
     const size_t per = (size_t)h * w, fper = (size_t)gp.fh * gp.fw;
     const double t0 = now_s();
-    parallel_images(k, [&](int i) { medial_axis_thin(b.filt_host[slot] + i * per, b.dist_host[slot] + i * per, h, w, b.skel_host[slot] + i * per); });
-    const double t1 = now_s();
     hipSetDevice(c->device);
     hipStream_t s = c->stream3;
-    bool ok = hipMemcpyAsync(b.skel[slot], b.skel_host[slot], k * per, hipMemcpyHostToDevice, s) == hipSuccess;
+    bool ok = true;
+    if (thin_on_device(c)) {
+        // host part of the medial axis: the RandomState(0) tie-break permutation of every image's foreground count
+        parallel_images(k, [&](int i) {
+            std::vector<uint32_t> perm;
+            legacy_permutation(0, (size_t)b.nfg_host[slot][i], perm);
+            std::memcpy(b.tie_host[slot] + i * per, perm.data(), perm.size() * sizeof(uint32_t));
+        });
+        for (int i = 0; i < k && ok; i++)
+            ok = hipMemcpyAsync(b.tie + i * per, b.tie_host[slot] + i * per, (size_t)b.nfg_host[slot][i] * sizeof(uint32_t), hipMemcpyHostToDevice, s) == hipSuccess;
+        ok = ok && thin_dev(b.filt[slot], b.dist[slot], b.tie, b.nfg[slot], k, h, w, b.thin_ws, c->ma_table, b.skel[slot], s) == 0;
+    } else {
+        parallel_images(k, [&](int i) { medial_axis_thin(b.filt_host[slot] + i * per, b.dist_host[slot] + i * per, h, w, b.skel_host[slot] + i * per); });
+        ok = hipMemcpyAsync(b.skel[slot], b.skel_host[slot], k * per, hipMemcpyHostToDevice, s) == hipSuccess;
+    }
+    const double t1 = now_s();
     ok = ok && finish_dev(b.pred[slot], b.dist[slot], b.skel[slot], k, h, w, gp.fh, gp.fw, b.finish_ws, b.field[slot], b.f255[slot], s) == 0;
     ok = ok && hipMemcpyAsync(b.f255_host[slot], b.f255[slot], k * fper * sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess;
     // DMT front end on the device: edge keys + lower-star sort from the field in HBM; the sorted edge ids come back
@@ -222,7 +262,7 @@ static void run_pass_host(Ctx *c, int slot, int k, const GraphParams gp, tmat_ro
         if (rc) job->rc = rc;
     });
     if (trace_on())
-        fprintf(stderr, "[tmat] host pass (%d images): thinning %.1f ms, GPU finish %.1f ms, DMT + Morse %.1f ms\n", k, (t1 - t0) * 1e3,
+        fprintf(stderr, "[tmat] host pass (%d images): thinning (host part) %.1f ms, GPU thinning/finish/DMT front %.1f ms, DMT + Morse %.1f ms\n", k, (t1 - t0) * 1e3,
                 (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
 }
 
@@ -241,6 +281,7 @@ static int analyze_dev(Ctx *c, const uint16_t *imgs_dev, int n, int H, int W, do
     const int K = std::min(n, std::max(1, c->max_patches / g.tiles_per_img));      // one image per pass when it needs > max_patches
     { int rc0 = ensure_patch_io(c, K * g.tiles_per_img); if (rc0) return rc0; }
     int rc = ensure_pass_buffers(c, K, H, W, h, w, gp.fh, gp.fw);
+    if (!rc) rc = ensure_ma_table(c);
     if (rc) return rc;
     for (int i = 0; i < n; i++) { rows[i].index = first_index + i; rows[i].count = 0; rows[i].total_px = 0; rows[i].avg_px = 0; }
     const int P = (n + K - 1) / K;
@@ -270,6 +311,29 @@ static int analyze_dev(Ctx *c, const uint16_t *imgs_dev, int n, int H, int W, do
     for (auto &j : jobs) { j.join(); if (j.rc && !rc) rc = j.rc; }
     hipStreamSynchronize(c->stream2);
     hipStreamSynchronize(c->stream);
+    return rc;
+}
+
+// medial_axis on the device for k masks that are in HBM with their EDT: foreground counts -> host permutations -> keys,
+// sort, ordered thinning (thin_kernels.hip).  Synchronises the stream once (the counts come back to the host).
+static int medial_thin_batch_dev(Ctx *c, const uint8_t *mask_dev, const double *dist_dev, int k, int hh, int ww, uint8_t *skel_dev, hipStream_t s)
+{
+    int rc = ensure_ma_table(c);
+    if (rc) return rc;
+    const size_t per = (size_t)hh * ww;
+    int *nfg = nullptr; uint32_t *tie = nullptr; void *ws = nullptr;
+    std::vector<int> nfg_host(k, 0);
+    if (!hip_ok(hipMalloc((void **)&nfg, k * sizeof(int)), "hipMalloc") || !hip_ok(hipMalloc((void **)&tie, k * per * sizeof(uint32_t)), "hipMalloc") ||
+        !hip_ok(hipMalloc(&ws, thin_workspace_bytes(k, hh, ww)), "hipMalloc")) rc = TMAT_E_HIP;
+    if (!rc && thin_count_dev(mask_dev, k, hh, ww, nfg, s)) rc = TMAT_E_HIP;
+    if (!rc && (!hip_ok(hipMemcpyAsync(nfg_host.data(), nfg, k * sizeof(int), hipMemcpyDeviceToHost, s), "D2H") || !hip_ok(hipStreamSynchronize(s), "sync"))) rc = TMAT_E_HIP;
+    std::vector<std::vector<uint32_t>> perms(k);
+    if (!rc) parallel_images(k, [&](int i) { legacy_permutation(0, (size_t)nfg_host[i], perms[i]); });
+    for (int i = 0; i < k && !rc; i++)
+        if (!perms[i].empty() && !hip_ok(hipMemcpyAsync(tie + i * per, perms[i].data(), perms[i].size() * sizeof(uint32_t), hipMemcpyHostToDevice, s), "H2D")) rc = TMAT_E_HIP;
+    if (!rc && thin_dev(mask_dev, dist_dev, tie, nfg, k, hh, ww, ws, c->ma_table, skel_dev, s)) { set_error("medial axis: device thinning failed"); rc = TMAT_E_HIP; }
+    if (!rc && !hip_ok(hipStreamSynchronize(s), "sync")) rc = TMAT_E_HIP;      // perms / scratch are released below
+    hipFree(nfg); hipFree(tie); hipFree(ws);
     return rc;
 }
 
@@ -472,13 +536,41 @@ int tmat_postprocess_batch(tmat_handle hd, const double *pred, int n, int hh, in
             !hip_ok(hipStreamSynchronize(s), "sync")) { rc = TMAT_E_HIP; break; }
         for (int i = 0; i < k && !rc; i++) if (!conv[i]) { set_error("tmat_postprocess_batch: thinning did not converge"); rc = TMAT_E_HIP; }
         if (rc) break;
-        parallel_images(k, [&](int i) { medial_axis_thin(filt.data() + i * per, dist.data() + i * per, hh, ww, skel.data() + i * per); });
-        if (!hip_ok(hipMemcpyAsync(dsk, skel.data(), k * per, hipMemcpyHostToDevice, s), "H2D")) { rc = TMAT_E_HIP; break; }
+        if (c->thin_device && thin_dev_supported(hh, ww)) {
+            rc = medial_thin_batch_dev(c, df, dd, k, hh, ww, dsk, s);
+            if (rc) break;
+        } else {        // images too large for the LDS-resident thinning kernel: host threads
+            parallel_images(k, [&](int i) { medial_axis_thin(filt.data() + i * per, dist.data() + i * per, hh, ww, skel.data() + i * per); });
+            if (!hip_ok(hipMemcpyAsync(dsk, skel.data(), k * per, hipMemcpyHostToDevice, s), "H2D")) { rc = TMAT_E_HIP; break; }
+        }
         if (finish_dev(dp, dd, dsk, k, hh, ww, out_h, out_w, fws, dfield, d255, s)) { rc = TMAT_E_HIP; break; }
         if (!hip_ok(hipMemcpyAsync(field + (size_t)i0 * oper, dfield, k * oper * 4, hipMemcpyDeviceToHost, s), "D2H") ||
             !hip_ok(hipStreamSynchronize(s), "sync")) rc = TMAT_E_HIP;
     }
     hipFree(dp); hipFree(dd); hipFree(df); hipFree(dsk); hipFree(ws); hipFree(fws); hipFree(dfield); hipFree(d255);
+    return rc;
+}
+
+int tmat_medial_axis_batch(tmat_handle hd, const uint8_t *mask, int n, int hh, int ww, uint8_t *skel, double *dist)
+{
+    Ctx *c = (Ctx *)hd;
+    if (!c || !mask || !skel || !dist || n < 0 || hh < 1 || ww < 1) { set_error("tmat_medial_axis_batch: bad argument"); return TMAT_E_ARG; }
+    if (n == 0) return TMAT_OK;
+    if (!thin_dev_supported(hh, ww)) { set_error("tmat_medial_axis_batch: image too large for the device thinning kernel (use tmat_host_medial_axis)"); return TMAT_E_ARG; }
+    TMAT_HIP(hipSetDevice(c->device));
+    const size_t npx = (size_t)n * hh * ww;
+    uint8_t *dm = nullptr, *dsk = nullptr; double *dd = nullptr; int *g = nullptr, *anyz = nullptr;
+    int rc = TMAT_OK;
+    hipStream_t s = c->stream;
+    if (!hip_ok(hipMalloc((void **)&dm, npx), "hipMalloc") || !hip_ok(hipMalloc((void **)&dsk, npx), "hipMalloc") ||
+        !hip_ok(hipMalloc((void **)&dd, npx * 8), "hipMalloc") || !hip_ok(hipMalloc((void **)&g, npx * sizeof(int)), "hipMalloc") ||
+        !hip_ok(hipMalloc((void **)&anyz, n * sizeof(int)), "hipMalloc")) rc = TMAT_E_HIP;
+    if (!rc && !hip_ok(hipMemcpyAsync(dm, mask, npx, hipMemcpyHostToDevice, s), "H2D")) rc = TMAT_E_HIP;
+    if (!rc) launch_edt(dm, n, hh, ww, g, nullptr, anyz, dd, s);
+    if (!rc) rc = medial_thin_batch_dev(c, dm, dd, n, hh, ww, dsk, s);
+    if (!rc && (!hip_ok(hipMemcpyAsync(skel, dsk, npx, hipMemcpyDeviceToHost, s), "D2H") ||
+                !hip_ok(hipMemcpyAsync(dist, dd, npx * 8, hipMemcpyDeviceToHost, s), "D2H") || !hip_ok(hipStreamSynchronize(s), "sync"))) rc = TMAT_E_HIP;
+    hipFree(dm); hipFree(dsk); hipFree(dd); hipFree(g); hipFree(anyz);
     return rc;
 }
 

@@ -385,6 +385,13 @@ static const uint8_t *medial_table()
     return table;
 }
 
+void medial_table_bits(uint32_t out[16])
+{
+    const uint8_t *t = medial_table();
+    for (int i = 0; i < 16; i++) out[i] = 0;
+    for (int i = 0; i < 512; i++) if (t[i]) out[i >> 5] |= 1u << (i & 31);
+}
+
 void medial_axis(const uint8_t *m, int H, int W, uint8_t *skel, double *dist)
 {
     edt(m, H, W, dist);

@@ -15,6 +15,7 @@ void filter_mask(const uint8_t *mask_in, int H, int W, bool use_median, bool rem
 void edt(const uint8_t *m, int H, int W, double *dist);
 void legacy_permutation(uint32_t seed, size_t n, std::vector<uint32_t> &perm);
 void medial_axis(const uint8_t *m, int H, int W, uint8_t *skel, double *dist);
+void medial_table_bits(uint32_t out[16]);          // the 512 decisions of the medial-axis table, bit idx of word idx >> 5
 void medial_axis_thin(const uint8_t *m, const double *dist, int H, int W, uint8_t *skel);
 void postprocess_from_filtered(const double *pred, const uint8_t *filt, const double *dist, int H, int W, int oh, int ow, float *field);
 void resize_aa(const double *img, int H, int W, int oh, int ow, float *out);

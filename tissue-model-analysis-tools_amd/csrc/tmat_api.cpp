@@ -454,6 +454,7 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
     c->max_patches = max_patches > 0 ? max_patches : 400;
     if (const char *e = getenv("TMAT_FUSED_SEP")) c->fused_sep = atoi(e) != 0;
     if (const char *e = getenv("TMAT_DMT_DEVICE")) c->dmt_device = atoi(e) != 0;
+    if (const char *e = getenv("TMAT_THIN_DEVICE")) c->thin_device = atoi(e) != 0;
     if (!hip_ok(hipStreamCreate(&c->stream), "hipStreamCreate") || !build_model(c, m)) { tmat_destroy((tmat_handle)c); return TMAT_E_WEIGHTS; }
     // activation workspace: per patch (P/2)^2 * f0 floats for buf0/buf1 and twice that for buf2/buf3
     const size_t unit = (size_t)(patch / 2) * (patch / 2) * c->f0;
@@ -532,6 +533,7 @@ void tmat_destroy(tmat_handle h)
     if (c->patch_out) hipFree(c->patch_out);
     if (c->scratch) hipFree(c->scratch);
     if (c->win1d) hipFree(c->win1d);
+    if (c->ma_table) hipFree(c->ma_table);
     c->free_pass();
     for (auto &e : c->ev_open) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
     for (auto e : c->ev_pool) hipEventDestroy(e);

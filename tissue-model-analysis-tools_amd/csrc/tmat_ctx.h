@@ -48,6 +48,12 @@ struct PassBuf {
     uint8_t *skel_host[2] = {nullptr, nullptr};
     float *field[2] = {nullptr, nullptr}, *f255[2] = {nullptr, nullptr};
     float *f255_host[2] = {nullptr, nullptr};
+    // ordered thinning on the device (thin_kernels.hip): foreground counts, RandomState(0) permutations (host-made), scratch
+    void *thin_ws = nullptr;
+    int *nfg[2] = {nullptr, nullptr};
+    int *nfg_host[2] = {nullptr, nullptr};
+    uint32_t *tie = nullptr;
+    uint32_t *tie_host[2] = {nullptr, nullptr};
     // DMT front end (dmt_kernels.hip): lower-star sorted edge ids of every image of the pass, counts of kept edges
     void *dmt_ws = nullptr;
     int32_t *dmt_ids[2] = {nullptr, nullptr};
@@ -87,7 +93,7 @@ struct Ctx {
         PassBuf &b = pass;
         void *dev[] = {b.xi, b.yi, b.xc, b.yc, b.tmp, b.x, b.small, b.mn, b.mx, b.pred[0], b.pred[1], b.morph_ws,
                        b.filt[0], b.filt[1], b.dist[0], b.dist[1], b.finish_ws, b.skel[0], b.skel[1], b.field[0], b.field[1],
-                       b.f255[0], b.f255[1], b.dmt_ws, b.dmt_ids[0], b.dmt_ids[1], b.dmt_m[0], b.dmt_m[1]};
+                       b.f255[0], b.f255[1], b.dmt_ws, b.dmt_ids[0], b.dmt_ids[1], b.dmt_m[0], b.dmt_m[1], b.thin_ws, b.nfg[0], b.nfg[1], b.tie};
         for (void *p : dev) if (p) hipFree(p);
         for (int i = 0; i < 2; i++) {
             if (b.pred_host[i]) hipHostFree(b.pred_host[i]);
@@ -98,10 +104,14 @@ struct Ctx {
             if (b.f255_host[i]) hipHostFree(b.f255_host[i]);
             if (b.dmt_ids_host[i]) hipHostFree(b.dmt_ids_host[i]);
             if (b.dmt_m_host[i]) hipHostFree(b.dmt_m_host[i]);
+            if (b.nfg_host[i]) hipHostFree(b.nfg_host[i]);
+            if (b.tie_host[i]) hipHostFree(b.tie_host[i]);
             if (b.done[i]) hipEventDestroy(b.done[i]);
         }
         pass = PassBuf();
     }
+    bool thin_device = true;                                 // ordered medial-axis thinning on the device (TMAT_THIN_DEVICE=0: host threads)
+    uint32_t *ma_table = nullptr;                            // its 512-entry decision table, 16 words
     bool dmt_device = true;                                  // DMT key build + lower-star sort on the device (TMAT_DMT_DEVICE=0: host)
     bool fused_sep = true;                                   // fused depthwise->pointwise kernel where the level allows (TMAT_FUSED_SEP=0: off)
     // profiling of the dominant kernel family

@@ -54,6 +54,13 @@ void launch_minmax_f32(const float *x, int n, size_t per, float *mn, float *mx, 
 void launch_extract_tiles(const float *x, const float *padval, int n, const TileGeom &g, float *patches, hipStream_t s);
 void launch_blend(const float *pred_patches, const double *win1d, int n, const TileGeom &g, double *out, hipStream_t s);
 
+// ---- ordered medial-axis thinning on the device (thin_kernels.hip) ------------------------------------
+bool thin_dev_supported(int H, int W);
+size_t thin_workspace_bytes(int n, int H, int W);
+int thin_count_dev(const uint8_t *mask, int n, int H, int W, int *nfg, hipStream_t s);
+int thin_dev(const uint8_t *mask, const double *dist, const uint32_t *tie, const int *nfg, int n, int H, int W, void *ws,
+             const uint32_t *table_dev, uint8_t *skel, hipStream_t s);
+
 // ---- DMT front end on the device (dmt_kernels.hip) -------------------------------------------------
 inline size_t dmt_edge_count(int R, int C) { return (size_t)(R - 1) * C + (size_t)R * (C - 1) + (size_t)(R - 1) * (C - 1); }
 size_t dmt_workspace_bytes(int n, int R, int C);

@@ -49,6 +49,7 @@ def lib():
     L.tmat_segment_batch.argtypes = [vp, vp, i, i, i, C.c_double, vp]
     L.tmat_postprocess_batch.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.tmat_filter_edt_batch.argtypes = [vp, vp, i, i, i, vp, vp]
+    L.tmat_medial_axis_batch.argtypes = [vp, vp, i, i, i, vp, vp]
     L.tmat_finish_batch.argtypes = [vp, vp, vp, vp, i, i, i, i, i, vp, vp]
     L.tmat_filter_mask_batch.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.tmat_gather_rows.argtypes = [vp, vp, i, vp, vp]
@@ -74,7 +75,7 @@ def lib():
 
 EXPORTS = [
     "tmat_last_error", "tmat_version", "tmat_create", "tmat_create_plain", "tmat_destroy", "tmat_sync", "tmat_set_input_depth", "tmat_unet_predict",
-    "tmat_predict_smooth", "tmat_segment_batch", "tmat_postprocess_batch", "tmat_filter_edt_batch", "tmat_finish_batch", "tmat_filter_mask_batch", "tmat_zproj_batch", "tmat_zproj_dev", "tmat_gather_rows",
+    "tmat_predict_smooth", "tmat_segment_batch", "tmat_postprocess_batch", "tmat_filter_edt_batch", "tmat_medial_axis_batch", "tmat_finish_batch", "tmat_filter_mask_batch", "tmat_zproj_batch", "tmat_zproj_dev", "tmat_gather_rows",
     "tmat_dmt_graph", "tmat_morse_stats",
     "tmat_analyze_batch_dev", "tmat_analyze_batch", "tmat_dev_alloc", "tmat_dev_free", "tmat_dev_upload",
     "tmat_prof_enable", "tmat_prof_read", "tmat_host_lanczos4_u16", "tmat_host_rescale01_u16",
@@ -138,6 +139,14 @@ class Handle:
         check(lib().tmat_predict_smooth(self._h, ptr(xb), xb.shape[0], xb.shape[1], xb.shape[2], ptr(out)),
               "tmat_predict_smooth")
         return out[0] if single else out
+
+    def medial_axis(self, mask: np.ndarray):
+        """tmat_medial_axis_batch: mask (n, h, w) bool/u8 -> (skel (n, h, w) bool, dist (n, h, w) f64), on the device"""
+        m = np.ascontiguousarray(mask, np.uint8)
+        skel = np.empty(m.shape, np.uint8)
+        dist = np.empty(m.shape, np.float64)
+        check(lib().tmat_medial_axis_batch(self._h, ptr(m), m.shape[0], m.shape[1], m.shape[2], ptr(skel), ptr(dist)), "tmat_medial_axis_batch")
+        return skel.astype(bool), dist
 
     def filter_edt(self, pred: np.ndarray):
         """GPU binary morphology: pred (n, h, w) f64 -> (filtered mask bool, EDT f64)"""
