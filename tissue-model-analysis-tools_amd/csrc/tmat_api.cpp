@@ -455,7 +455,12 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
     if (const char *e = getenv("TMAT_FUSED_SEP")) c->fused_sep = atoi(e) != 0;
     if (const char *e = getenv("TMAT_DMT_DEVICE")) c->dmt_device = atoi(e) != 0;
     if (const char *e = getenv("TMAT_THIN_DEVICE")) c->thin_device = atoi(e) != 0;
-    if (!hip_ok(hipStreamCreate(&c->stream), "hipStreamCreate") || !build_model(c, m)) { tmat_destroy((tmat_handle)c); return TMAT_E_WEIGHTS; }
+    // the UNet stream gets the highest priority, the side stream of the post-processing stages (thinning rounds, finish,
+    // DMT front end: many short launches that only have to be done before the next pass ends) the lowest: they fill the
+    // gaps instead of taking workgroup slots from the MFMA kernels
+    int prio_least = 0, prio_greatest = 0;
+    hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (!hip_ok(hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_greatest), "hipStreamCreate") || !build_model(c, m)) { tmat_destroy((tmat_handle)c); return TMAT_E_WEIGHTS; }
     // activation workspace: per patch (P/2)^2 * f0 floats for buf0/buf1 and twice that for buf2/buf3
     const size_t unit = (size_t)(patch / 2) * (patch / 2) * c->f0;
     const size_t sizes[4] = {unit, unit, 2 * unit, 2 * unit};
@@ -475,7 +480,7 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
         if (!hip_ok(hipMalloc((void **)&c->dout[i], dsz * c->max_patches * sizeof(float)), "hipMalloc(dout)")) {
             tmat_destroy((tmat_handle)c); return TMAT_E_HIP;
         }
-    if (!hip_ok(hipStreamCreate(&c->stream2), "hipStreamCreate(2)") || !hip_ok(hipStreamCreate(&c->stream3), "hipStreamCreate(3)")) {
+    if (!hip_ok(hipStreamCreate(&c->stream2), "hipStreamCreate(2)") || !hip_ok(hipStreamCreateWithPriority(&c->stream3, hipStreamDefault, prio_least), "hipStreamCreate(3)")) {
         tmat_destroy((tmat_handle)c); return TMAT_E_HIP;
     }
     for (int i = 0; i < 2; i++)

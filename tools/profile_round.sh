@@ -8,6 +8,7 @@ ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/profiles_$R
 mkdir -p $OUT
 cd $ROOT
+if [ "$2" != "pmc-only" ]; then
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
@@ -15,9 +16,14 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R
 find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 rm -rf $OUT/trace            # the raw per-dispatch trace is large; the stats summary is what is kept
 echo "kernel-trace done"
+fi
+# PMC passes (separate runs, --kernel-trace only beside --pmc) on the UNet forward alone: the same kernels with the same
+# 1600-patch launches as in the pipeline (tools/gpu_quick.py), without the many short morphology / thinning launches,
+# each of which costs milliseconds under counter collection
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
   tag=$(echo $grp | cut -d' ' -f1)
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_$tag -- python3 $ROOT/bench.py --images 16 --distinct 4 --no-cpu-baseline > $OUT/pmc_$tag.json 2> $OUT/pmc_$tag.err || echo "pmc $tag failed"
+  echo "pmc $tag ..."
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_$tag -- python3 $ROOT/tools/gpu_quick.py 1600 2 > $OUT/pmc_$tag.json 2> $OUT/pmc_$tag.err || echo "pmc $tag failed"
   find $OUT/pmc_$tag -name "*counter_collection.csv" | head -1 | xargs -I{} cp {} $OUT/pmc_$tag.csv || true
   find $OUT/pmc_$tag -name "*kernel_trace.csv" | head -1 | xargs -I{} cp {} $OUT/pmc_${tag}_trace.csv || true
   rm -rf $OUT/pmc_$tag

@@ -22,7 +22,12 @@ def main(rnd):
         if (src / name).exists():
             shutil.copy(src / name, dst / f"{rnd}_{name}")
     out = {"round": rnd, "dominant_kernel": "tmat::" + DOM}
-    for r in csv.DictReader(open(src / "kernel_stats.csv")):
+    rows = list(csv.DictReader(open(src / "kernel_stats.csv")))
+    rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+    out["top_kernels_by_total_time"] = [
+        {"kernel": r["Name"].split("(")[0].replace("void ", ""), "calls": int(r["Calls"]), "total_ms": round(float(r["TotalDurationNs"]) / 1e6, 1),
+         "avg_ms": round(float(r["AverageNs"]) / 1e6, 3), "percent": float(r["Percentage"])} for r in rows[:8]]
+    for r in rows:
         if DOM in r["Name"]:
             out["rocprof_calls"] = int(r["Calls"])
             out["rocprof_avg_ms"] = float(r["AverageNs"]) / 1e6
@@ -52,8 +57,8 @@ def main(rnd):
         out["hbm_read_bytes_per_launch"] = fetch
         out["hbm_write_bytes_per_launch"] = write
         out["traffic_bytes_per_launch"] = fetch + write
-        out["traffic_note"] = ("mean over the launches of the dominant kernel in a 16-image run of the same pipeline "
-                               "(same 1600 patches per launch); FETCH_SIZE x2 per MI355X_MICROARCH.md, WRITE_SIZE as read")
+        out["traffic_note"] = ("mean over the launches of the dominant kernel in two UNet forwards of 1600 patches (tools/gpu_quick.py: the "
+                               "same launches as in the pipeline); FETCH_SIZE x2 per MI355X_MICROARCH.md, WRITE_SIZE as read")
     mf = counter("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES")
     ga = counter("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE")
     if mf and ga:
