@@ -284,6 +284,65 @@ def gen_zstacks():
 
 
 
+# --------------------------------------------------------------------------------------------
+# sato group: the scikit-image functions of the Z-stack branch (compute_branches.py:224-306), stage by stage, from the
+# scikit-image 0.18.3 of /opt/conda/bin/python3.9 (the reference pins 0.22.0, which is not importable anywhere here).
+# --------------------------------------------------------------------------------------------
+def sato_inputs():
+    """deterministic small inputs, regenerated by the tests from the seeds"""
+    from scipy import ndimage as ndi
+    rs = np.random.RandomState(41)
+
+    def tubes(shape, n, seed):
+        r = np.random.RandomState(seed)
+        a = np.zeros(shape)
+        yy, xx = np.mgrid[: shape[0], : shape[1]]
+        for _ in range(n):
+            y0, x0, th = r.uniform(0, shape[0]), r.uniform(0, shape[1]), r.uniform(0, np.pi)
+            d = np.abs((yy - y0) * np.cos(th) - (xx - x0) * np.sin(th))
+            a += r.uniform(0.3, 1.0) * np.exp(-(d / r.uniform(1.0, 3.5)) ** 2)
+        a += 0.05 * ndi.gaussian_filter(r.normal(size=shape), 1.0)
+        a -= a.min()
+        return (a / a.max()).astype(np.float32)
+    imgs = {"t1": tubes((96, 128), 6, 1), "t2": tubes((80, 80), 3, 2)}
+    vol = np.stack([tubes((64, 80), 4, 10) * w for w in (0.4, 0.8, 1.0, 0.7, 0.3)]).astype(np.float32)
+    return imgs, vol
+
+
+def gen_sato():
+    from skimage.feature import canny
+    from skimage.filters import gaussian, sato, unsharp_mask
+    from skimage.morphology import closing, dilation, disk, square
+    from fl_tissue_model_tools import transforms
+    imgs, vol = sato_inputs()
+    out = {}
+    import warnings
+    warnings.simplefilter("ignore")
+    for k, im in imgs.items():
+        out[k + "_sato"] = sato(im, sigmas=[1, 2, 3, 4, 5, 7, 9, 11, 13, 15], black_ridges=False).astype(np.float32)
+        out[k + "_sato135"] = sato(im, sigmas=[1, 3, 5], black_ridges=False).astype(np.float32)
+        out[k + "_gauss"] = gaussian(im)
+    vess = np.stack([sato(np.maximum(vol[z], vol[z + 1]), sigmas=[1, 2, 3], black_ridges=False) for z in range(len(vol) - 1)]).astype(np.float32)
+    sharp = unsharp_mask(vess, 2, 2)
+    out["vol_sharp"] = sharp
+    vessels = sharp.max(0)
+    edges = canny(vessels, sigma=0)
+    out["vol_edges"] = np.packbits(edges)
+    out["t1_edges"] = np.packbits(canny(out["t1_sato"], sigma=0))
+    from skimage.morphology import medial_axis
+    skel = medial_axis(edges)
+    out["vol_skel"] = np.packbits(skel)
+    ecc = transforms.regionprops_image(skel, "eccentricity")
+    dia = transforms.regionprops_image(skel, "equivalent_diameter")
+    out["vol_eccdiam"] = (ecc * dia).astype(np.float64)
+    rs = np.random.RandomState(3)
+    m = rs.uniform(size=(60, 70)) > 0.7
+    out["m_closed"] = np.packbits(closing(m.astype(np.int64), disk(2)).astype(bool))
+    out["m_dil"] = np.packbits(dilation(m, square(3)))
+    np.savez_compressed(GOLD / "sato.npz", **out)
+    print("sato.npz", {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     GOLD.mkdir(parents=True, exist_ok=True)
     _shims()
