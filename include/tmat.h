@@ -110,11 +110,12 @@ int tmat_filter_mask_batch(tmat_handle h, const uint8_t *mask, int n, int hh, in
 /*
  * skimage.morphology.medial_axis(mask, return_distance=True) (reference call compute_branches.py:340; scikit-image
  * 0.18.3 semantics with the RandomState(0) tie-break) for a batch, on the device: exact EDT (morph_kernels.hip), then the
- * ordered thinning (thin_kernels.hip: sort keys from distance / corner score / tie-break, stable radix sort, one wave
- * per image walking the order with the mask as an LDS bitmap).  Only the tie-break permutation (a Mersenne-Twister
- * shuffle that depends on the foreground COUNT alone) is produced on the host.  mask, skel (n, h, w) u8; dist (n, h, w)
- * f64.  Images whose bitmaps do not fit LDS (beyond about 1400 x 1400) are refused here; the pipeline runs those
- * through the host implementation (tmat_host_medial_axis).  A handle from tmat_create_plain is enough.
+ * ordered thinning (thin_kernels.hip: keys from distance / corner score / tie-break; a pixel's decision depends only on
+ * its 8 neighbours with smaller keys, so the removal order is resolved as a dependency wavefront in strict Jacobi rounds).
+ * Only the tie-break permutation (a Mersenne-Twister shuffle that depends on the foreground COUNT alone) is produced on
+ * the host.  mask, skel (n, h, w) u8; dist (n, h, w) f64.  Images with h^2 + w^2 >= 2^27 are refused here (the squared
+ * distance no longer fits its key field); the pipeline runs those through the host implementation
+ * (tmat_host_medial_axis).  A handle from tmat_create_plain is enough.
  */
 int tmat_medial_axis_batch(tmat_handle h, const uint8_t *mask, int n, int hh, int ww, uint8_t *skel, double *dist);
 
@@ -175,6 +176,71 @@ int tmat_analyze_batch(tmat_handle h, const uint16_t *imgs, int n, int H, int W,
                        float graph_thresh_1, float graph_thresh_2, int smoothing_window_px,
                        int min_branch_length_px, int max_branch_length_px, int remove_isolated,
                        int64_t first_index, tmat_row *rows);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Z-stack (Sato) branch of analyze_img: reference scripts/compute_branches.py:224-306 (csrc/sato_kernels.hip,
+ * csrc/stack_pipeline.cpp).  Its arithmetic lives in scikit-image / scipy.ndimage (reference setup.py pins
+ * scikit-image==0.22.0, scipy==1.13.1); oracle/sato.py restates it.  A handle from tmat_create_plain is enough.
+ * --------------------------------------------------------------------------------------------------------------- */
+
+/* Hessian of skimage.filters.sato: 0 = gaussian derivatives (scikit-image >= 0.20, what the pinned 0.22.0 runs:
+ * hessian_matrix(use_gaussian_derivatives=True), -image, vesselness sigma^2 * max(l1, 0));  1 = gradient of the smoothed
+ * image (scikit-image <= 0.19: gaussian, np.gradient twice, 1 - image, sigma^2-scaled elements). */
+#define TMAT_SATO_GAUSSIAN_DERIVATIVES 0
+#define TMAT_SATO_GRADIENT 1
+/* scipy.ndimage boundary modes of tmat_gaussian_f32 */
+#define TMAT_EXT_NEAREST 0
+#define TMAT_EXT_REFLECT 1
+#define TMAT_EXT_MIRROR 2
+
+/*
+ * Replace the kernel table of scipy's gaussian_filter1d for (sigma, order, radius) on this handle: weights = the 2 radius + 1
+ * values scipy hands to correlate1d (ndimage/_filters.py:_gaussian_kernel1d(sigma, order, radius)[::-1]).  Without it the
+ * library forms the table with libm's exp; numpy's exp is CPU-dispatched and differs from libm in the last bit at some taps,
+ * so a host that wants scipy's exact results on its machine hands over numpy-made tables (tmat_amd/sato.py does).
+ */
+int tmat_set_gaussian_table(tmat_handle h, double sigma, int order, int radius, const double *weights);
+/* the library's own table (host only): scipy's formula with libm's exp and numpy's pairwise sum; order 0 or 1 */
+int tmat_host_gaussian_kernel1d(double sigma, int order, int radius, double *weights);
+
+/* skimage.filters.gaussian(x, sigma, mode) on a float32 array (d0, d1, d2) (= ndi.gaussian_filter, truncate 4, f64
+ * accumulation, f32 after every axis); d0 = 1 filters a 2-D image (d1, d2).  compute_branches.py:248, 269, 282, 302 */
+int tmat_gaussian_f32(tmat_handle h, const float *x, int d0, int d1, int d2, double sigma, int mode, float *out);
+
+/* skimage.filters.sato(img, sigmas, black_ridges=False) on n float32 images (n, h, w) (compute_branches.py:261-263) */
+int tmat_sato_batch(tmat_handle h, const float *imgs, int n, int hh, int ww, const double *sigmas, int n_sigmas, int hessian,
+                    float *out);
+
+/* compute_branches.py:247-256: per-slice gaussian written back into the integer stack, skimage resize of the stack to
+ * (Z, out_h, out_w) (order 1, anti-aliased, preserve_range), rescale_intensity(0..1) over the stack.
+ * stack (Z, H, W) u16 host (8-bit stacks widened); vol (Z, out_h, out_w) f32 host. */
+int tmat_stack_prepare(tmat_handle h, const uint16_t *stack, int Z, int H, int W, int out_h, int out_w, float *vol);
+
+/* optional host copies of the stages of tmat_vessel_field (any member may be NULL) */
+typedef struct tmat_vessel_stages {
+    float *vess;       /* (Z-1, h, w) Sato response of every slice pair          :258-266 */
+    float *sharp;      /* (Z-1, h, w) unsharp_mask(vess, 2, 2)                   :269     */
+    float *vessels;    /* (h, w) its max projection                               :270     */
+    uint8_t *edges;    /* (h, w) canny(vessels, sigma=0)                          :271     */
+    uint8_t *skel;     /* (h, w) medial_axis(edges)                               :274     */
+    uint8_t *mask_sel; /* (h, w) components with eccentricity * diameter > 3.5    :276-279 */
+    uint8_t *grown;    /* (h, w) after the 10 region-growing rounds               :283-294 */
+    uint8_t *closed;   /* (h, w) closing(mask & ~edges, disk(2))                  :296-297 */
+    uint8_t *filt;     /* (h, w) filter_branch_seg_mask(closed, None, False)      :299     */
+} tmat_vessel_stages;
+
+/* compute_branches.py:258-302: prepared stack vol (Z, h, w) f32 in 0..1 -> vesselness image field (h, w) f32 */
+int tmat_vessel_field(tmat_handle h, const float *vol, int Z, int hh, int ww, int hessian, float *field,
+                      const tmat_vessel_stages *stages);
+
+/*
+ * The whole per-image compute of analyze_img for a Z stack (compute_branches.py:224-306, 391-426, 455-457; no well
+ * mask): stack (Z, H, W) u16 host -> one result row.  The field is (round(H ds_width / W), ds_width); the graph
+ * parameters are those of tmat_analyze_batch.  field_out (nullable) receives the vesselness image.
+ */
+int tmat_analyze_stack(tmat_handle h, const uint16_t *stack, int Z, int H, int W, int ds_width, int hessian,
+                       float graph_thresh_1, float graph_thresh_2, int smoothing_window_px, int min_branch_length_px,
+                       int max_branch_length_px, int remove_isolated, int64_t index, tmat_row *row, float *field_out);
 
 /* device memory helpers so a ctypes host can stage inputs in HBM without torch */
 int tmat_dev_alloc(tmat_handle h, size_t bytes, void **dev_ptr);

@@ -15,10 +15,13 @@ restates those functions with numpy + scipy.ndimage so that the goldens pin it:
                                  (mode 'mirror') over the scaled axes, grid-mode linear zoom, clip to the range of the WHOLE
                                  stack.  (0.18.3's own nD resize maps corner to corner -- ndi.zoom without grid_mode -- and is
                                  NOT what the pinned 0.22 does; this stage is therefore pinned to scipy, not to the goldens.)
-  filters.sato (2-D)          -> 1 - image (util.invert on unsigned-float data), gaussian_filter(mode 'reflect') per sigma,
-                                 np.gradient twice, sigma^2 scaling, closed-form eigenvalues of the 2x2 Hessian
-                                 (feature/corner.py:_image_orthogonal_matrix22_eigvals), max over sigma of max(l_max, 0);
-                                 all in float32, in numpy's operation order
+  filters.sato (2-D)          -> two forms.  "gradient" (scikit-image <= 0.19, pinned by the goldens): 1 - image
+                                 (util.invert), gaussian_filter(mode 'reflect') per sigma, np.gradient twice, sigma^2 scaling,
+                                 closed-form eigenvalues (feature/corner.py:_image_orthogonal_matrix22_eigvals), max over
+                                 sigma of max(l_max, 0); all in float32, in numpy's operation order.  "gaussian_derivatives"
+                                 (>= 0.20, what the pinned 0.22.0 runs; the default of vessel_field): see sato2d_derivatives --
+                                 restated from the published source, every primitive the real scipy call, the composition
+                                 PARITY UNPINNED (no fixture of this branch in the reference, no scikit-image >= 0.20 here)
   filters.unsharp_mask        -> image + (image - gaussian(image, 2, mode 'reflect')) * 2, clipped to 0..1, on the 3-D volume
   feature.canny(sigma=0)      -> feature/_canny.py restated (sobel, 4-sector non-maximum suppression, 0.1 / 0.2 thresholds,
                                  hysteresis through 8-connected labels)
@@ -48,20 +51,17 @@ def gaussian(img: np.ndarray, sigma=1.0, mode="nearest") -> np.ndarray:
 
 def stack_prepare(stack: np.ndarray, out_hw) -> np.ndarray:
     """compute_branches.py:247-257: per-slice gaussian written back into the INTEGER stack (C truncation), resize to
-    (Z, out_h, out_w), rescale to 0..1 over the whole stack, float32"""
+    (Z, out_h, out_w) -- scikit-image >= 0.19's resize is these two scipy calls on the 3-D array, the Z axis with sigma 0 and
+    zoom 1 -- clip to the stack's range, rescale to 0..1 over the whole stack, float32"""
     st = np.array(stack, copy=True)
     for i in range(len(st)):
         st[i, :] = gaussian(st[i], 1.0)                                    # float64 -> integer dtype: truncation
     vol = st.astype(np.float64)
-    factors = np.divide(vol.shape[1:], out_hw)
+    out_shape = (len(vol),) + tuple(int(v) for v in out_hw)
+    factors = np.divide(vol.shape, out_shape)
     sig = np.maximum(0, (factors - 1) / 2)
-    out = np.empty((len(vol),) + tuple(out_hw), np.float64)
-    for z in range(len(vol)):
-        filt = vol[z]
-        for ax in (0, 1):
-            if sig[ax] > 0:
-                filt = morph.correlate1d_sym(filt, morph.gaussian_kernel1d(float(sig[ax])), ax)
-        out[z] = morph.zoom_linear_grid(filt, tuple(out_hw))
+    filt = ndi.gaussian_filter(vol, sig, cval=0, mode="mirror")
+    out = ndi.zoom(filt, [1 / f for f in factors], order=1, mode="mirror", cval=0, grid_mode=True)
     out = np.clip(out, vol.min(), vol.max())
     return morph.rescale_intensity(out, (0, 1)).astype(np.float32)
 
@@ -78,14 +78,41 @@ def hessian_eigmax(inv: np.ndarray, sigma: int) -> np.ndarray:
     return (m00 + m11) / 2 + np.sqrt(4 * m01 ** 2 + (m00 - m11) ** 2) / 2
 
 
-def sato2d(im: np.ndarray, sigmas=SATO_SIGMAS) -> np.ndarray:
-    """skimage.filters.sato(im, sigmas, black_ridges=False) for a 2-D float32 image; float32 values"""
+def sato2d_gradient(im: np.ndarray, sigmas=SATO_SIGMAS) -> np.ndarray:
+    """skimage.filters.sato(im, sigmas, black_ridges=False) of scikit-image <= 0.19 for a 2-D float32 image (pinned by the
+    0.18.3 goldens): Hessian = np.gradient twice of the gaussian-smoothed inverted image"""
     inv = F32(1) - im.astype(np.float32)
     best = np.zeros(im.shape, np.float32)
     for s in sigmas:
         l1 = hessian_eigmax(inv, s)
         best = np.maximum(best, np.where(l1 > 0, np.abs(l1), F32(0)))
     return best
+
+
+def sato2d_derivatives(im: np.ndarray, sigmas=SATO_SIGMAS) -> np.ndarray:
+    """the same call under scikit-image >= 0.20 (the reference pins 0.22.0), restated from the published source
+    (filters/ridges.py:sato, feature/corner.py:_hessian_matrix_with_gaussian, _symmetric_compute_eigenvalues): image = -image;
+    Hessian by two successive first-order gaussian-derivative filters of sigma / sqrt(2) (truncate 8, or 100 when sigma <= 1,
+    mode 'reflect'); eigenvalues (M00 + M11) / 2 +- sqrt(M01^2 + ((M00 - M11) / 2)^2); vesselness sigma^2 * max(l_max, 0).
+    PARITY UNPINNED as a composition: no scikit-image >= 0.20 is importable here and the reference holds no fixture of this
+    branch; each primitive below is the real scipy call."""
+    img = -im.astype(np.float32)
+    best = np.zeros(im.shape, np.float32)
+    sq1_2 = 1 / math.sqrt(2)
+    for s in sigmas:
+        kw = dict(sigma=(sq1_2 * s, sq1_2 * s), mode="reflect", cval=0, truncate=8 if s > 1 else 100)
+        g0 = ndi.gaussian_filter(img, order=[1, 0], **kw)
+        g1 = ndi.gaussian_filter(img, order=[0, 1], **kw)
+        m00 = ndi.gaussian_filter(g0, order=[1, 0], **kw)
+        m01 = ndi.gaussian_filter(g0, order=[0, 1], **kw)
+        m11 = ndi.gaussian_filter(g1, order=[0, 1], **kw)
+        l1 = (m00 + m11) / 2 + np.sqrt(m01 ** 2 + ((m00 - m11) / 2) ** 2)
+        best = np.maximum(best, F32(s ** 2) * np.maximum(l1, F32(0)))
+    return best
+
+
+def sato2d(im: np.ndarray, sigmas=SATO_SIGMAS, hessian="gradient") -> np.ndarray:
+    return sato2d_gradient(im, sigmas) if hessian == "gradient" else sato2d_derivatives(im, sigmas)
 
 
 def unsharp_mask(vol: np.ndarray, radius=2, amount=2) -> np.ndarray:
@@ -198,38 +225,38 @@ def region_grow(mask: np.ndarray, vessels: np.ndarray, iters=10) -> np.ndarray:
     return m
 
 
-def vessel_field(vol01: np.ndarray, return_stages=False):
+def vessel_field(vol01: np.ndarray, return_stages=False, hessian="gaussian_derivatives"):
     """compute_branches.py:259-305 from the prepared float32 stack (Z, h, w) to the float32 vesselness image"""
     Z = len(vol01)
     vess = np.zeros((Z - 1,) + vol01.shape[1:], np.float32)
     for z in range(Z - 1):
-        vess[z] = sato2d(np.maximum(vol01[z], vol01[z + 1]))
+        vess[z] = sato2d(np.maximum(vol01[z], vol01[z + 1]), SATO_SIGMAS, hessian)
     sharp = unsharp_mask(vess, 2, 2)
     vessels = sharp.max(0)
     edges = canny0(vessels)
     skel, _ = morph.medial_axis(edges)
-    mask = skel & (ecc_times_diameter(skel) > 3.5)
+    sel = skel & (ecc_times_diameter(skel) > 3.5)
+    mask = sel
     v = vessels
     for _ in range(3):
         v = np.where(mask, gaussian(v), v)
-    mask = region_grow(mask, v, 10)
-    mask &= ~edges
+    grown = region_grow(mask, v, 10)
+    mask = grown & ~edges
     d2 = disk(2)
     closed = ndi.grey_erosion(ndi.grey_dilation(mask.astype(np.uint8), footprint=d2), footprint=d2).astype(bool)
     filt = morph.filter_branch_seg_mask(closed, use_median=False, remove_isolated=False)
     dil = ndi.grey_dilation(filt.astype(np.uint8), footprint=np.ones((3, 3), bool)).astype(bool)
-    field = gaussian(np.where(dil, sharp.max(0), F32(0)).astype(np.float32))
+    field = gaussian(np.where(dil, vessels, F32(0)).astype(np.float32))
     if return_stages:
-        return field, dict(vess=vess, sharp=sharp, vessels=vessels, edges=edges, skel=skel, mask_sel=skel & (ecc_times_diameter(skel) > 3.5),
-                           grown=mask, closed=closed, filt=filt)
+        return field, dict(vess=vess, sharp=sharp, vessels=vessels, edges=edges, skel=skel, mask_sel=sel, grown=grown, closed=closed, filt=filt)
     return field
 
 
-def analyze_stack(stack: np.ndarray, config: dict, image_width_microns: float):
+def analyze_stack(stack: np.ndarray, config: dict, image_width_microns: float, hessian="gaussian_derivatives"):
     """(count, total_px, avg_px) of one Z stack through the Sato branch + the graph stages of the 2-D path"""
     from . import dmt, morse, pipeline
     out_hw = morph.dsamp_shape(stack.shape[-2:], 384)
-    field = vessel_field(stack_prepare(stack, out_hw))
+    field = vessel_field(stack_prepare(stack, out_hw), hessian=hessian)
     f255 = morph.rescale_intensity(field, (0, 255)).astype(np.float32)
     V, E = dmt.compute_dmt_graph(f255, float(config.get("graph_thresh_1", 5)), float(config.get("graph_thresh_2", 10)))
     sw, mn, mx = pipeline.px_params(config, 384, image_width_microns)

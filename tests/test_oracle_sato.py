@@ -83,3 +83,35 @@ def test_vessel_field_runs_end_to_end():
     field, st = sato.vessel_field(VOL, return_stages=True)
     assert field.dtype == np.float32 and field.shape == VOL.shape[1:] and np.isfinite(field).all()
     assert st["edges"].any() and field.max() > 0
+
+
+def test_stack_prepare_3d_scipy_calls_equal_the_per_slice_form():
+    """the resize of the 3-D stack (Z sigma 0, Z zoom 1) is the 2-D anti-aliased resize of every slice, clipped to the range
+    of the WHOLE stack: that is what the device path computes (csrc/stack_pipeline.cpp:stack_prepare_dev)"""
+    from scipy import ndimage as ndi
+    rs = np.random.RandomState(5)
+    stack = (rs.uniform(0, 1, (4, 70, 90)) ** 3 * 60000).astype(np.uint16)
+    out_hw = (30, 38)
+    vol = sato.stack_prepare(stack, out_hw)
+    assert vol.dtype == np.float32 and vol.shape == (4, 30, 38) and vol.min() == 0 and vol.max() == 1
+    st = stack.copy()
+    for i in range(len(st)):
+        st[i, :] = ndi.gaussian_filter(st[i].astype(np.float64), 1.0, mode="nearest")
+    per = np.stack([morph.resize_aa_scipy(st[i], out_hw) for i in range(len(st))])     # clips per slice ...
+    fz = np.divide(st.shape[1:], out_hw)
+    raw = np.stack([ndi.zoom(ndi.gaussian_filter(st[i].astype(np.float64), np.maximum(0, (fz - 1) / 2), mode="mirror"),
+                             [1 / f for f in fz], order=1, mode="mirror", grid_mode=True) for i in range(len(st))])
+    raw = np.clip(raw, st.min(), st.max())                                              # ... the stack form clips globally
+    assert np.array_equal(morph.rescale_intensity(raw, (0, 1)).astype(np.float32), vol)
+    assert per.shape == raw.shape
+
+
+def test_derivative_form_responds_to_ridges_like_the_gradient_form():
+    """scikit-image >= 0.20's Hessian (PARITY UNPINNED as a composition, see oracle/sato.py): both forms estimate the same
+    second derivative, so on smooth tubes they agree to within the discretisation error, are non-negative and peak on ridges"""
+    im = IMGS["t1"]
+    a = sato.sato2d(im, (2, 3, 5), "gradient")
+    b = sato.sato2d(im, (2, 3, 5), "gaussian_derivatives")
+    assert b.dtype == np.float32 and b.min() >= 0
+    assert np.corrcoef(a.ravel(), b.ravel())[0, 1] > 0.97
+    assert abs(float(b.max()) / float(a.max()) - 1) < 0.25

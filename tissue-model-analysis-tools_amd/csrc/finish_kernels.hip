@@ -9,6 +9,7 @@
 #include "tmat_internal.h"
 #include "morph.h"
 #include "postproc.h"
+#include "tmat_ctx.h"
 
 #include <cmath>
 
@@ -123,6 +124,27 @@ size_t finish_workspace_bytes(int k, int H, int W, int oh, int ow)
            (size_t)(oh + ow) * 2 * (sizeof(int) + sizeof(double)) + 4096 * sizeof(double) + 8192;
 }
 
+// scipy zoom(order=1, mode='mirror', grid_mode=True) along one axis: source coordinate (j + 0.5) * (in/out) - 0.5, the two taps
+// and their weights (1 - t, 1 - (1 - t))
+void zoom_axis_table(int n_in, int n_out, std::vector<int> &i0, std::vector<int> &i1, std::vector<double> &a0, std::vector<double> &a1)
+{
+    auto mir = [](long i, int n) { if (n == 1) return 0; const long p = 2L * (n - 1); i %= p; if (i < 0) i += p; return (int)(i < n ? i : p - i); };
+    const double zoom = (double)n_in / (double)n_out;
+    i0.resize(n_out); i1.resize(n_out); a0.resize(n_out); a1.resize(n_out);
+    for (int j = 0; j < n_out; j++) {
+        const double cc = ((double)j + 0.5) * zoom - 0.5;
+        const double fl = std::floor(cc), tt = cc - fl;
+        a0[j] = 1.0 - tt; a1[j] = 1.0 - a0[j];
+        i0[j] = mir((long)fl, n_in); i1[j] = mir((long)fl + 1, n_in);
+    }
+}
+void launch_rescale255(const float *field, int k, int npx, float *mn, float *mx, float *out, hipStream_t s)
+{
+    const dim3 grid((npx + 255) / 256 < 1024 ? (npx + 255) / 256 : 1024, k);
+    hipLaunchKernelGGL((minmax_kernel<float>), dim3(k), dim3(256), 0, s, field, (size_t)npx, mn, mx);
+    hipLaunchKernelGGL(rescale255_kernel, grid, dim3(256), 0, s, field, npx, mn, mx, out);
+}
+
 // host-built tables, cached per geometry
 struct FinishTables {
     int H = 0, W = 0, oh = 0, ow = 0;
@@ -141,25 +163,14 @@ static void build_tables(FinishTables &t, int H, int W, int oh, int ow)
         const double s2 = sigma * sigma;
         double tot = 0.0;
         for (int x = -r; x <= r; x++) w[x + r] = std::exp(-0.5 / s2 * (double)(x * x));
-        for (double v : w) tot += v;
+        tot = numpy_pairwise_sum(w.data(), (long)w.size());       // phi_x.sum() in scipy's _gaussian_kernel1d
         for (double &v : w) v = v / tot;
     };
     const double f0 = (double)H / (double)oh, f1 = (double)W / (double)ow;
     gk(std::max(0.0, (f0 - 1) / 2), t.w0);
     gk(std::max(0.0, (f1 - 1) / 2), t.w1);
-    auto mir = [](long i, int n) { if (n == 1) return 0; const long p = 2L * (n - 1); i %= p; if (i < 0) i += p; return (int)(i < n ? i : p - i); };
-    auto axis = [&](int n_in, int n_out, std::vector<int> &i0, std::vector<int> &i1, std::vector<double> &a0, std::vector<double> &a1) {
-        const double zoom = (double)n_in / (double)n_out;
-        i0.resize(n_out); i1.resize(n_out); a0.resize(n_out); a1.resize(n_out);
-        for (int j = 0; j < n_out; j++) {
-            const double cc = ((double)j + 0.5) * zoom - 0.5;
-            const double fl = std::floor(cc), tt = cc - fl;
-            a0[j] = 1.0 - tt; a1[j] = 1.0 - a0[j];
-            i0[j] = mir((long)fl, n_in); i1[j] = mir((long)fl + 1, n_in);
-        }
-    };
-    axis(H, oh, t.r0, t.r1, t.wr0, t.wr1);
-    axis(W, ow, t.c0, t.c1, t.wc0, t.wc1);
+    zoom_axis_table(H, oh, t.r0, t.r1, t.wr0, t.wr1);
+    zoom_axis_table(W, ow, t.c0, t.c1, t.wc0, t.wc1);
 }
 
 // pred, dist (k, H, W) f64 device; skel (k, H, W) u8 device -> field (k, oh, ow) f32 (before a17) and f255 (after), device

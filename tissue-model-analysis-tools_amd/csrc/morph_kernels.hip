@@ -125,6 +125,16 @@ __global__ void ccl_compress_kernel(int *__restrict__ L, int npx)
     IMG_LOOP(p, npx) { if (L[base + p] >= 0) L[base + p] = uf_find(L + base, p); }
 }
 
+// 8-connected labels of k masks: L = smallest pixel index of the component (per image), -1 on the background
+void launch_ccl(const uint8_t *mask, int k, int H, int W, int *L, hipStream_t s)
+{
+    const int npx = H * W;
+    const dim3 grid((npx + 255) / 256 < 1024 ? (npx + 255) / 256 : 1024, k), blk(256);
+    hipLaunchKernelGGL(ccl_init_kernel, grid, blk, 0, s, mask, L, H, W);
+    hipLaunchKernelGGL(ccl_merge_kernel, grid, blk, 0, s, mask, L, H, W);
+    hipLaunchKernelGGL(ccl_compress_kernel, grid, blk, 0, s, L, npx);
+}
+
 // ---- per-label area and perimeter code counts (skimage regionprops.perimeter, 4-neighbourhood) ----
 __device__ __forceinline__ int lab_at(const int *L, int H, int W, int y, int x) { return (y < 0 || y >= H || x < 0 || x >= W) ? -1 : L[y * W + x]; }
 __device__ __forceinline__ bool is_border(const int *L, int H, int W, int y, int x, int l)

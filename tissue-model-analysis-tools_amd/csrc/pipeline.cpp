@@ -316,7 +316,7 @@ static int analyze_dev(Ctx *c, const uint16_t *imgs_dev, int n, int H, int W, do
 
 // medial_axis on the device for k masks that are in HBM with their EDT: foreground counts -> host permutations -> keys,
 // sort, ordered thinning (thin_kernels.hip).  Synchronises the stream once (the counts come back to the host).
-static int medial_thin_batch_dev(Ctx *c, const uint8_t *mask_dev, const double *dist_dev, int k, int hh, int ww, uint8_t *skel_dev, hipStream_t s)
+int medial_thin_batch_dev(Ctx *c, const uint8_t *mask_dev, const double *dist_dev, int k, int hh, int ww, uint8_t *skel_dev, hipStream_t s)
 {
     int rc = ensure_ma_table(c);
     if (rc) return rc;

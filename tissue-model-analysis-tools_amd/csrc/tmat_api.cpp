@@ -539,6 +539,7 @@ void tmat_destroy(tmat_handle h)
     if (c->scratch) hipFree(c->scratch);
     if (c->win1d) hipFree(c->win1d);
     if (c->ma_table) hipFree(c->ma_table);
+    for (auto &g : c->gauss_dev) hipFree(g.second);
     c->free_pass();
     for (auto &e : c->ev_open) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
     for (auto e : c->ev_pool) hipEventDestroy(e);

@@ -1,6 +1,7 @@
 // Handle state of libtmat_hip.so.
 #pragma once
 #include "tmat_internal.h"
+#include "gauss_tables.h"
 
 #include <map>
 
@@ -63,8 +64,15 @@ struct PassBuf {
     hipEvent_t done[2] = {nullptr, nullptr};
 };
 
+struct GaussKey {
+    double sigma; int order, radius;
+    bool operator<(const GaussKey &o) const { return sigma != o.sigma ? sigma < o.sigma : order != o.order ? order < o.order : radius < o.radius; }
+};
+
 struct Ctx {
     int device = 0;
+    std::map<GaussKey, GaussTable> gauss;                    // gaussian kernel tables (gauss_tables.cpp)
+    std::map<const GaussTable *, double *> gauss_dev;        // their device copies (stack_pipeline.cpp)
     hipStream_t stream = nullptr;
     int patch = 0, max_patches = 0;
     int f0 = 0, f_last = 0;

@@ -63,6 +63,14 @@ def lib():
     L.tmat_dev_alloc.argtypes = [vp, sz, C.POINTER(vp)]
     L.tmat_dev_free.argtypes = [vp, vp]
     L.tmat_dev_upload.argtypes = [vp, vp, vp, sz]
+    d = C.c_double
+    L.tmat_set_gaussian_table.argtypes = [vp, d, i, i, vp]
+    L.tmat_host_gaussian_kernel1d.argtypes = [d, i, i, vp]
+    L.tmat_gaussian_f32.argtypes = [vp, vp, i, i, i, d, i, vp]
+    L.tmat_sato_batch.argtypes = [vp, vp, i, i, i, vp, i, i, vp]
+    L.tmat_stack_prepare.argtypes = [vp, vp, i, i, i, i, i, vp]
+    L.tmat_vessel_field.argtypes = [vp, vp, i, i, i, i, vp, vp]
+    L.tmat_analyze_stack.argtypes = [vp, vp, i, i, i, i, i, f, f, i, i, i, i, C.c_int64, vp, vp]
     L.tmat_prof_enable.argtypes = [vp, i]
     L.tmat_prof_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), i]
     for name in EXPORTS:
@@ -81,6 +89,8 @@ EXPORTS = [
     "tmat_prof_enable", "tmat_prof_read", "tmat_host_lanczos4_u16", "tmat_host_rescale01_u16",
     "tmat_host_rescale255_f32", "tmat_host_filter_mask", "tmat_host_skeletonize", "tmat_host_medial_axis",
     "tmat_host_permutation", "tmat_host_postprocess",
+    "tmat_set_gaussian_table", "tmat_host_gaussian_kernel1d", "tmat_gaussian_f32", "tmat_sato_batch", "tmat_stack_prepare", "tmat_vessel_field",
+    "tmat_analyze_stack",
 ]
 
 
@@ -92,6 +102,11 @@ def check(rc: int, what: str = ""):
 
 def ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
+
+
+class VesselStages(C.Structure):
+    """tmat_vessel_stages (include/tmat.h)"""
+    _fields_ = [(k, C.c_void_p) for k in ("vess", "sharp", "vessels", "edges", "skel", "mask_sel", "grown", "closed", "filt")]
 
 
 class Handle:

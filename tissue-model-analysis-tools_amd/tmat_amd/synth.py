@@ -89,6 +89,33 @@ def synth_image(index: int, size: int = 1024, n_vessels: int = 40, scale: float 
     return np.clip(img, 0, 65535).astype(np.uint16)
 
 
+def synth_stack(index: int, n_slices: int = 12, height: int = 512, width: int = 512, n_vessels: int = 14) -> np.ndarray:
+    """uint16 (Z, height, width) synthetic confocal-like Z stack, deterministic in `index`: curved tubes that each live in a
+    few neighbouring slices (gaussian profile along Z), plus sensor noise"""
+    from scipy.ndimage import gaussian_filter
+
+    rs = np.random.RandomState(4321 + index)
+    scale = width / 1024.0
+    vol = np.zeros((n_slices, height, width), np.float64)
+    tt = np.linspace(0.0, 1.0, int(900 * scale) + 60)[:, None]
+    b0, b1, b2, b3 = (1 - tt) ** 3, 3 * (1 - tt) ** 2 * tt, 3 * (1 - tt) * tt**2, tt**3
+    yy, xx = np.mgrid[:height, :width]
+    for _ in range(n_vessels):
+        ctrl = rs.uniform(0, 1, (4, 2)) * (height, width)
+        pts = b0 * ctrl[0] + b1 * ctrl[1] + b2 * ctrl[2] + b3 * ctrl[3]
+        plane = np.zeros((height, width))
+        iy = np.clip(np.round(pts[:, 0]).astype(int), 0, height - 1)
+        ix = np.clip(np.round(pts[:, 1]).astype(int), 0, width - 1)
+        plane[iy, ix] = 1.0
+        plane = gaussian_filter(plane, rs.uniform(3.0, 8.0) * scale + 0.8)
+        plane /= plane.max()
+        zc, zw = rs.uniform(0, n_slices - 1), rs.uniform(1.0, 2.5)
+        prof = np.exp(-(((np.arange(n_slices) - zc) / zw) ** 2))
+        vol += rs.uniform(15000, 45000) * prof[:, None, None] * plane[None]
+    vol += 1500.0 + rs.normal(0.0, 400.0, vol.shape)
+    return np.clip(vol, 0, 65535).astype(np.uint16)
+
+
 # --------------------------------------------------------------------------------------
 # weights
 # --------------------------------------------------------------------------------------
