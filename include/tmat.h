@@ -242,6 +242,13 @@ int tmat_analyze_stack(tmat_handle h, const uint16_t *stack, int Z, int H, int W
                        float graph_thresh_1, float graph_thresh_2, int smoothing_window_px, int min_branch_length_px,
                        int max_branch_length_px, int remove_isolated, int64_t index, tmat_row *row, float *field_out);
 
+/* The common tail of analyze_img from a vesselness image (compute_branches.py:391-426, 455-457): rescale to 0..255, DMT
+ * graph, MorseGraph statistics -> one row.  field (fh, fw) f32 host.  Lets a host that sweeps the graph_thresh grid
+ * (:366-395) compute the field once. */
+int tmat_field_stats(tmat_handle h, const float *field, int fh, int fw, float graph_thresh_1, float graph_thresh_2,
+                     int smoothing_window_px, int min_branch_length_px, int max_branch_length_px, int remove_isolated,
+                     int64_t index, tmat_row *row);
+
 /* device memory helpers so a ctypes host can stage inputs in HBM without torch */
 int tmat_dev_alloc(tmat_handle h, size_t bytes, void **dev_ptr);
 int tmat_dev_free(tmat_handle h, void *dev_ptr);

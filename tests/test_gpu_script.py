@@ -90,15 +90,58 @@ def test_script_takes_the_width_from_tiff_metadata(tmp_path, handle):
         assert float(got[2]) == pytest.approx(branches.pixels_to_microns(w[2], 384, width), rel=1e-12)
 
 
-def test_script_refuses_z_stacks(tmp_path):
-    """a directory of z-numbered slice sequences goes to the reference's Sato branch, which this path does not provide"""
+def _oracle_stack_row(stack, width_um, hessian="gaussian_derivatives", t1=5, t2=10):
+    from oracle import sato as osato
+    from tmat_amd import branches
+    cfg = {"graph_thresh_1": t1, "graph_thresh_2": t2, "graph_smoothing_window": 12, "min_branch_length": 12, "remove_isolated_branches": False}
+    n, tot, avg = osato.analyze_stack(stack, cfg, width_um, hessian=hessian)
+    return n, branches.pixels_to_microns(tot, 384, width_um), branches.pixels_to_microns(avg, 384, width_um)
+
+
+def test_script_analyzes_z_stacks_through_the_sato_branch(tmp_path):
+    """a directory of z-numbered slice sequences (compute_branches.py:547-553) goes through the Z-stack branch: one CSV row per
+    stack, equal to the oracle's restatement of the branch; --visualizations writes the branch's two pictures"""
     from PIL import Image
-    ind = tmp_path / "in"
+    from tmat_amd import synth
+    ind, outd = tmp_path / "in", tmp_path / "out"
     ind.mkdir()
-    for z in range(3):
-        Image.fromarray(np.zeros((64, 64), np.uint16)).save(ind / f"well_z{z}.tif")
-    r = run([str(ind), str(tmp_path / "o"), "--image-width-microns", "100"])
-    assert r.returncode == 1 and "Z stacks" in r.stdout
+    stacks = {"wellA": synth.synth_stack(1, 4, 200, 256, n_vessels=8), "wellB": synth.synth_stack(2, 3, 200, 256, n_vessels=8)}
+    for k, st in stacks.items():
+        for z, sl in enumerate(st):
+            Image.fromarray(sl).save(ind / f"{k}_z{z}.tif")
+    r = run([str(ind), str(outd), "--image-width-microns", "800", "--visualizations"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = read_csv(outd / "branching_analysis.csv")
+    assert [x[0] for x in rows[1:]] == ["wellA", "wellB"]
+    for got in rows[1:]:
+        n, tot, avg = _oracle_stack_row(stacks[got[0]], 800.0)
+        assert int(got[1]) == n and float(got[2]) == pytest.approx(tot, rel=1e-12) and float(got[3]) == pytest.approx(avg, rel=1e-12)
+        assert n > 0
+    for k, st in stacks.items():
+        vdir = outd / "visualizations" / k
+        assert sorted(p.name for p in vdir.iterdir()) == ["original_image.png", "vesselness_image.png"]
+        mx = st.max(0).astype(np.float64)
+        want = np.rint((mx - mx.min()) / (mx.max() - mx.min()) * 255.0).astype(np.uint8)
+        assert np.array_equal(np.array(Image.open(vdir / "original_image.png")), want)
+        assert np.array(Image.open(vdir / "vesselness_image.png")).shape == (300, 384)
+
+
+def test_script_multipage_stacks_threshold_grid_and_legacy_hessian(tmp_path):
+    """multi-page TIFF files are stacks too (compute_branches.py:554-559); a threshold grid writes one CSV per configuration
+    from ONE vesselness image per stack; --sato-hessian gradient selects the scikit-image <= 0.19 Hessian"""
+    from PIL import Image
+    from tmat_amd import synth
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir()
+    st = synth.synth_stack(5, 5, 180, 240, n_vessels=8)
+    pages = [Image.fromarray(sl) for sl in st]
+    pages[0].save(ind / "stackfile.tif", save_all=True, append_images=pages[1:])
+    r = run([str(ind), str(outd), "--image-width-microns", "600", "--graph-thresh-1", "2", "5", "--sato-hessian", "gradient"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    for t1 in (2, 5):
+        rows = read_csv(outd / f"branching_analysis_CONFIG_thresh1_{t1}.0.csv")
+        n, tot, avg = _oracle_stack_row(st, 600.0, "gradient", t1=t1)
+        assert rows[1][0] == "stackfile" and int(rows[1][1]) == n and float(rows[1][2]) == pytest.approx(tot, rel=1e-12)
 
 
 def test_script_visualizations_and_time_refusal(tmp_path, handle, weights):

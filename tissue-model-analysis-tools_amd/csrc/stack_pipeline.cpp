@@ -337,6 +337,52 @@ int tmat_vessel_field(tmat_handle hd, const float *vol, int Z, int hh, int ww, i
     return TMAT_OK;
 }
 
+// common tail of analyze_img from the vesselness image in HBM: rescale_intensity(0..255) (:419), DMT graph, MorseGraph statistics
+static int field_stats_dev(Ctx *c, const float *field, int fh, int fw, float t1, float t2, int smooth, int min_len, int max_len, int remove_isolated,
+                           int64_t index, tmat_row *row, hipStream_t s)
+{
+    const size_t npx = (size_t)fh * fw, nE = dmt_edge_count(fh, fw);
+    Arena A;
+    float *f255 = A.get<float>(npx), *mnmx = A.get<float>(2);
+    int32_t *ids = A.get<int32_t>(nE);
+    int *m = A.get<int>(1);
+    void *dws = nullptr;
+    if (A.ok && hip_ok(hipMalloc(&dws, dmt_workspace_bytes(1, fh, fw)), "hipMalloc")) A.ptrs.push_back(dws); else A.ok = false;
+    if (!A.ok) return TMAT_E_HIP;
+    launch_rescale255(field, 1, (int)npx, mnmx, mnmx + 1, f255, s);
+    std::vector<float> f255_host(npx);
+    std::vector<int32_t> ids_host(nE);
+    int m_host = 0;
+    if (dmt_sorted_edges_dev(f255, 1, fh, fw, dws, ids, m, s)) { set_error("field stats: DMT front end failed"); return TMAT_E_HIP; }
+    TMAT_HIP(hipMemcpyAsync(f255_host.data(), f255, npx * 4, hipMemcpyDeviceToHost, s));
+    TMAT_HIP(hipMemcpyAsync(ids_host.data(), ids, nE * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    TMAT_HIP(hipMemcpyAsync(&m_host, m, sizeof(int), hipMemcpyDeviceToHost, s));
+    TMAT_HIP(hipStreamSynchronize(s));
+    const int cap_v = (int)npx + 4, cap_e = 3 * (int)npx + 4;
+    std::vector<int32_t> V((size_t)cap_v * 2), E((size_t)cap_e * 2);
+    int nv = 0, ne = 0;
+    int rc = dmt_graph_host_sorted(f255_host.data(), fh, fw, t1, t2, ids_host.data(), m_host, V.data(), cap_v, E.data(), cap_e, &nv, &ne);
+    row->index = index; row->count = 0; row->total_px = 0; row->avg_px = 0;
+    if (!rc)
+        rc = tmat_morse_stats(V.data(), nv, E.data(), ne, fh, fw, smooth, min_len, max_len, remove_isolated, nullptr, &row->count, &row->total_px,
+                              &row->avg_px, nullptr, 0);
+    return rc;
+}
+
+int tmat_field_stats(tmat_handle hd, const float *field, int fh, int fw, float graph_thresh_1, float graph_thresh_2, int smoothing_window_px,
+                     int min_branch_length_px, int max_branch_length_px, int remove_isolated, int64_t index, tmat_row *row)
+{
+    Ctx *c = (Ctx *)hd;
+    if (!c || !field || !row || fh < 2 || fw < 2) { set_error("tmat_field_stats: bad argument"); return TMAT_E_ARG; }
+    TMAT_HIP(hipSetDevice(c->device));
+    Arena A;
+    float *df = A.get<float>((size_t)fh * fw);
+    if (!A.ok) return TMAT_E_HIP;
+    TMAT_HIP(hipMemcpyAsync(df, field, (size_t)fh * fw * 4, hipMemcpyHostToDevice, c->stream));
+    return field_stats_dev(c, df, fh, fw, graph_thresh_1, graph_thresh_2, smoothing_window_px, min_branch_length_px, max_branch_length_px, remove_isolated,
+                           index, row, c->stream);
+}
+
 int tmat_analyze_stack(tmat_handle hd, const uint16_t *stack, int Z, int H, int W, int ds_width, int hessian, float graph_thresh_1,
                        float graph_thresh_2, int smoothing_window_px, int min_branch_length_px, int max_branch_length_px, int remove_isolated,
                        int64_t index, tmat_row *row, float *field_out)
@@ -354,37 +400,15 @@ int tmat_analyze_stack(tmat_handle hd, const uint16_t *stack, int Z, int H, int 
     hipStream_t s = c->stream;
     Arena A;
     uint16_t *ds = A.get<uint16_t>(nin);
-    float *vol = A.get<float>((size_t)Z * npx), *field = A.get<float>(npx), *f255 = A.get<float>(npx), *mnmx = A.get<float>(2);
-    const size_t nE = dmt_edge_count(fh, fw);
-    void *dws = nullptr;
-    int32_t *ids = A.get<int32_t>(nE);
-    int *m = A.get<int>(1);
-    if (A.ok && hip_ok(hipMalloc(&dws, dmt_workspace_bytes(1, fh, fw)), "hipMalloc")) A.ptrs.push_back(dws); else A.ok = false;
+    float *vol = A.get<float>((size_t)Z * npx), *field = A.get<float>(npx);
     if (!A.ok) return TMAT_E_HIP;
     TMAT_HIP(hipMemcpyAsync(ds, stack, nin * 2, hipMemcpyHostToDevice, s));
     int rc = stack_prepare_dev(c, ds, Z, H, W, fh, fw, vol, s);
     if (!rc) rc = vessel_field_dev(c, vol, Z, fh, fw, hessian, field, nullptr, s);
     if (rc) return rc;
-    // common tail: rescale_intensity(0..255) (:419), DMT graph, MorseGraph statistics
-    launch_rescale255(field, 1, (int)npx, mnmx, mnmx + 1, f255, s);
-    std::vector<float> f255_host(npx);
-    std::vector<int32_t> ids_host(nE);
-    int m_host = 0;
-    if (dmt_sorted_edges_dev(f255, 1, fh, fw, dws, ids, m, s)) { set_error("tmat_analyze_stack: DMT front end failed"); return TMAT_E_HIP; }
-    TMAT_HIP(hipMemcpyAsync(f255_host.data(), f255, npx * 4, hipMemcpyDeviceToHost, s));
-    TMAT_HIP(hipMemcpyAsync(ids_host.data(), ids, nE * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    TMAT_HIP(hipMemcpyAsync(&m_host, m, sizeof(int), hipMemcpyDeviceToHost, s));
     if (field_out) TMAT_HIP(hipMemcpyAsync(field_out, field, npx * 4, hipMemcpyDeviceToHost, s));
-    TMAT_HIP(hipStreamSynchronize(s));
-    const int cap_v = (int)npx + 4, cap_e = 3 * (int)npx + 4;
-    std::vector<int32_t> V((size_t)cap_v * 2), E((size_t)cap_e * 2);
-    int nv = 0, ne = 0;
-    rc = dmt_graph_host_sorted(f255_host.data(), fh, fw, graph_thresh_1, graph_thresh_2, ids_host.data(), m_host, V.data(), cap_v, E.data(), cap_e, &nv, &ne);
-    row->index = index; row->count = 0; row->total_px = 0; row->avg_px = 0;
-    if (!rc)
-        rc = tmat_morse_stats(V.data(), nv, E.data(), ne, fh, fw, smoothing_window_px, min_branch_length_px, max_branch_length_px, remove_isolated, nullptr,
-                              &row->count, &row->total_px, &row->avg_px, nullptr, 0);
-    return rc;
+    return field_stats_dev(c, field, fh, fw, graph_thresh_1, graph_thresh_2, smoothing_window_px, min_branch_length_px, max_branch_length_px,
+                           remove_isolated, index, row, s);
 }
 
 int tmat_host_gaussian_kernel1d(double sigma, int order, int radius, double *weights)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Analyze microvessels in a directory of 2-D Z-projections -- MI355X drop-in for the reference's
-scripts/compute_branches.py (2-D branch): same positional arguments, flags, config keys, CSV
-(utf-16, same header), config.json and exit behaviour (message + exit code 1).
+"""Analyze microvessels in a directory of 2-D Z-projections or of Z stacks -- MI355X drop-in for the reference's
+scripts/compute_branches.py: same positional arguments, flags, config keys, CSV (utf-16, same header), config.json and
+exit behaviour (message + exit code 1).  Projections go through the segmentation model (the 2-D branch,
+compute_branches.py:307-361); Z stacks (slice sequences with a z<number> token, or multi-page files) through the Sato
+branch (:224-306), both on the GPU.
 
     python compute_branches.py IN_ROOT OUT_ROOT [--image-width-microns F] [--graph-thresh-1 F ...]
         [--graph-thresh-2 F ...] [--min-branch-length F] [--max-branch-length F]
@@ -9,8 +11,9 @@ scripts/compute_branches.py (2-D branch): same positional arguments, flags, conf
 
 Differences (documented in INTEGRATION.md): images are analysed in batches on the GPU (one process
 per GPU under torch.distributed.run; rows are gathered over RCCL and rank 0 writes the CSV);
-Z-stack inputs and --detect-well are outside the accelerated path; the PNG image dumps are opt-in (--visualizations; the
-matplotlib barcode / tree plots are not reproduced);
+--detect-well is outside the accelerated path; the PNG image dumps are opt-in (--visualizations; the
+matplotlib barcode / tree plots are not reproduced); --sato-hessian picks the Hessian of skimage.filters.sato
+(gaussian_derivatives = scikit-image >= 0.20, what the reference's pinned 0.22.0 runs; gradient = <= 0.19);
 without --image-width-microns (or the config key) the width comes from OME / ImageJ TIFF metadata
 (tmat_amd/helper.py), as in the reference.
 """
@@ -53,6 +56,9 @@ def parse_branching_args(arg_defaults):
     p.add_argument("--visualizations", action="store_true",
                    help="also write visualizations/<image>/{original_image,prediction,segmentation_mask,distance_transform}.png "
                         "(the reference always does; here it is opt-in: it re-runs the image through the staged entry points)")
+    p.add_argument("--sato-hessian", choices=["gaussian_derivatives", "gradient"], default="gaussian_derivatives",
+                   help="Z stacks: Hessian of skimage.filters.sato -- gaussian_derivatives (scikit-image >= 0.20, the reference's pinned "
+                        "0.22.0) or gradient (scikit-image <= 0.19)")
     args = p.parse_args()
     if not args.remove_isolated_branches:
         args.remove_isolated_branches = None
@@ -111,6 +117,148 @@ def load_image_2d(path: str, channel=None, time=None) -> np.ndarray:
     return a        # uint8 images are widened at the ABI and flagged (input_bits=8): cv2.resize saturates to the source depth
 
 
+def n_planes(path: str) -> int:
+    """helper.get_image_dims(path).Z of the reference for the formats read here: pages of a TIFF, leading axis of a 3-D .npy"""
+    if path.endswith(".npy"):
+        a = np.load(path, mmap_mode="r")
+        return a.shape[0] if a.ndim == 3 and a.shape[0] > 4 and a.shape[-1] > 4 else 1
+    from PIL import Image
+    try:
+        with Image.open(path) as im:
+            return getattr(im, "n_frames", 1)
+    except OSError:
+        return 1
+
+
+def find_inputs(in_root: Path):
+    """compute_branches.py:547-566 -> (paths, is_stack): {stack id: [slice files] | multi-page file} or {stem: 2-D image file}"""
+    from tmat_amd import zstacks as zs
+    entries = sorted(glob(str(in_root / "*")))
+    test_path = entries[0]
+    if os.path.isdir(test_path) or n_planes(test_path) == 1:
+        try:
+            img_paths = zs.find_zstack_image_sequences(str(in_root))
+            if any(len(seq) == 1 for seq in img_paths.values()):
+                img_paths = {}          # not z stacks. probably projections.
+        except zs.ZStackInputException:
+            img_paths = {}
+    else:
+        try:
+            img_paths = zs.find_zstack_files(str(in_root))
+        except zs.ZStackInputException as exc:
+            print(f"{FAIL} {exc}", flush=True)
+            sys.exit(1)
+    if img_paths:
+        return img_paths, True
+    return {Path(fp).stem: fp for fp in entries if os.path.isfile(fp) and n_planes(fp) == 1}, False
+
+
+def load_stack(files, channel=None, time=None) -> np.ndarray:
+    """(Z, H, W) uint8 / uint16 stack of one Z-stack entry (reference helper.load_image with a list of slice files or one
+    multi-page file)"""
+    from tmat_amd import helper
+    if isinstance(files, str) and files.endswith(".npy"):
+        a = np.load(files)
+    else:
+        a, _ = helper.load_image(files, time, channel)
+    if a.ndim != 3:
+        raise ValueError(f"{np.atleast_1d(files)[0]}: expected a Z stack, got shape {a.shape}")
+    if a.dtype not in (np.uint8, np.uint16):
+        raise ValueError(f"{np.atleast_1d(files)[0]}: expected uint8/uint16 pixels, got {a.dtype}")
+    if a.shape[0] < 2:
+        raise ValueError(f"{np.atleast_1d(files)[0]}: a Z stack needs at least 2 slices")
+    return a
+
+
+def write_results(args, config, ids, gathered, out_root: Path, rank: int):
+    """the CSV per threshold configuration and config.json (compute_branches.py:459-500, 596-600), written by rank 0"""
+    from tmat_amd import branches
+    created = set()
+    for _, suffix in branches.threshold_grid(config):
+        rows = gathered[suffix]
+        if rank != 0:
+            continue
+        output_file = out_root / f"branching_analysis{suffix}.csv"
+        n = 1
+        while output_file.is_file() and str(output_file) not in created:
+            n += 1
+            output_file = out_root / f"branching_analysis{suffix}-{n}.csv"
+        create_output_csv(output_file)
+        created.add(str(output_file))
+        with open(output_file, "a", encoding="utf-16") as f:
+            wr = csv.writer(f, lineterminator="\n")
+            for gidx, cnt, tot_um, avg_um in rows:
+                wr.writerow([ids[gidx], cnt, tot_um, avg_um])
+        print(f"Results saved to {output_file}.", flush=True)
+    if rank == 0:
+        config["time"], config["channel"] = getattr(args, "time", None), getattr(args, "channel", None)
+        with open(get_unique_output_filepath(out_root / "config.json"), "w", encoding="utf8") as f:
+            json.dump({k: v for k, v in config.items() if v is not None}, f, indent=4)
+        print(f"{OK} Analysis complete.", flush=True)
+
+
+def finish_distributed(ws: int):
+    if ws > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_stacks(args, config, paths, out_root: Path, rank: int, ws: int, local_rank: int):
+    """Z-stack entries: the Sato branch (compute_branches.py:224-306) on this rank's share of the stacks"""
+    from tmat_amd import _lib, branches, helper, sato
+    handle = _lib.Handle(None, local_rank)          # this branch needs no segmentation model
+    hessian = getattr(args, "sato_hessian", "gaussian_derivatives")
+    vis = bool(getattr(args, "visualizations", False))
+    ids = sorted(paths)
+    fields = {}
+
+    def load_fn(img_id):
+        try:
+            return load_stack(paths[img_id], args.channel, args.time)
+        except (OSError, ValueError) as error:
+            print(f"{FAIL}{error}", flush=True)
+            sys.exit(1)
+
+    def width_fn(img_id, st):
+        width_um = config.get("image_width_microns")
+        if width_um is None:
+            px = helper.physical_pixel_sizes(np.atleast_1d(paths[img_id])[0]).X
+            if px is None:
+                print(f"{FAIL} The --image-width-microns parameter was not specified, and the pixel to micron conversion "
+                      f"factor was not found in the image metadata ({img_id}). Specify --image-width-microns and try again. "
+                      "Exiting...", flush=True)
+                sys.exit(1)
+            width_um = st.shape[-1] * px
+        return width_um
+
+    def analyze_fn(batch, width_um, thresh, input_bits):
+        # the vesselness image does not depend on the graph thresholds: one field per stack, swept over the grid
+        sw_px, min_px, max_px = branches.graph_px_params(config, DOWNSAMPLE_WIDTH, width_um)
+        rows = []
+        if fields.get("batch") is not batch:            # run_sharded hands the same array to every configuration of the grid
+            fields.clear()
+            fields["batch"] = batch
+        for i, st in enumerate(batch):
+            if i not in fields:
+                fields[i] = sato.stack_field(handle, st, DOWNSAMPLE_WIDTH, hessian)
+            rows.append((i,) + sato.field_stats(handle, fields[i], thresh[0], thresh[1], sw_px, min_px, max_px,
+                                                bool(config.get("remove_isolated_branches", False))))
+        return rows
+
+    def load_and_keep(img_id):
+        st = load_fn(img_id)
+        if vis:
+            branches.save_stack_visualizations(handle, st, out_root / "visualizations" / img_id, hessian)
+        return st
+
+    # one stack per analysis call (chunk=1): a stack is the unit the reference streams, and it can be gigabytes
+    gathered = branches.run_sharded(ids, load_and_keep, width_fn, analyze_fn, config, rank, ws, chunk=1, log=lambda m: print(m, flush=True))
+    write_results(args, config, ids, gathered, out_root, rank)
+    handle.close()
+    finish_distributed(ws)
+
+
 def main(args=None):
     if args is None:
         args = parse_branching_args({"default_config_path": DEFAULT_CONFIG_PATH})
@@ -146,21 +294,12 @@ def main(args=None):
     except PermissionError as e:
         print(f"{FAIL} {e}", flush=True)
         sys.exit(1)
-    paths = {Path(fp).stem: fp for fp in glob(str(in_root / "*")) if os.path.isfile(fp)}
-    if not paths:
+    if not glob(str(in_root / "*")):
         print(f"{FAIL}No images found in {in_root}", flush=True)
         sys.exit(1)
-    # The reference first looks for Z stacks (compute_branches.py:547-566): slice files with a z<number> token that form
-    # sequences of more than one slice, or multi-page files, go to its Sato branch, which is not part of this path.
-    from tmat_amd import zstacks as zs
-    try:
-        seqs = zs.find_zstack_image_sequences(str(in_root))
-        is_stack_dir = bool(seqs) and all(len(v) > 1 for v in seqs.values())
-    except zs.ZStackInputException:
-        is_stack_dir = False
-    if is_stack_dir:
-        print(f"{FAIL} {in_root} holds Z stacks (image sequences); the Z-stack branch of compute_branches is outside the "
-              "accelerated path. Project them first (compute_zproj.py) and analyse the projections.", flush=True)
+    paths, is_stack = find_inputs(in_root)
+    if not paths:
+        print(f"{FAIL}No images found in {in_root}", flush=True)
         sys.exit(1)
     # image_width_microns: the option / config key, else per image from the file's metadata (reference
     # compute_branches.py:184-212: img.shape[-1] * PhysicalPixelSizes.X), else the reference's failure message
@@ -175,6 +314,9 @@ def main(args=None):
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend)
+    if is_stack:
+        run_stacks(args, config, paths, out_root, rank, ws, local_rank)
+        return
     model = models.get_unet_patch_segmentor_from_cfg(model_cfg_path, device_id=local_rank)
     if model.norm_mean is not None and model.norm_std is not None:
         # models.py:636-637 normalises the image in predict(); the batched device path has no such stage
@@ -216,36 +358,11 @@ def main(args=None):
             branches.save_visualizations(model.handle, img, out_root / "visualizations" / img_id, model.ds_ratio, 8 * img.dtype.itemsize)
         return img
 
-    grid = branches.threshold_grid(config)
     gathered = branches.run_sharded(ids, load_and_keep, width_fn, analyze_fn, config, rank, ws,
                                     log=lambda m: print(m, flush=True))
-    created = set()
-    for _, suffix in grid:
-        rows = gathered[suffix]
-        if rank != 0:
-            continue
-        output_file = out_root / f"branching_analysis{suffix}.csv"
-        n = 1
-        while output_file.is_file() and str(output_file) not in created:
-            n += 1
-            output_file = out_root / f"branching_analysis{suffix}-{n}.csv"
-        create_output_csv(output_file)
-        created.add(str(output_file))
-        with open(output_file, "a", encoding="utf-16") as f:
-            wr = csv.writer(f, lineterminator="\n")
-            for gidx, cnt, tot_um, avg_um in rows:
-                wr.writerow([ids[gidx], cnt, tot_um, avg_um])
-        print(f"Results saved to {output_file}.", flush=True)
-    if rank == 0:
-        config["time"], config["channel"] = getattr(args, "time", None), getattr(args, "channel", None)
-        with open(get_unique_output_filepath(out_root / "config.json"), "w", encoding="utf8") as f:
-            json.dump({k: v for k, v in config.items() if v is not None}, f, indent=4)
-        print(f"{OK} Analysis complete.", flush=True)
+    write_results(args, config, ids, gathered, out_root, rank)
     model.handle.close()
-    if ws > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+    finish_distributed(ws)
 
 
 if __name__ == "__main__":

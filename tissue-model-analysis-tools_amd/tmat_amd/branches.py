@@ -158,3 +158,30 @@ def save_visualizations(handle: _lib.Handle, img: np.ndarray, vis_dir, ds_ratio:
         return str(file)
     return [save_vis(original, "original_image.png"), save_vis(pred[0], "prediction.png"),
             save_vis(filt[0].astype(np.float64), "segmentation_mask.png"), save_vis(weighted, "distance_transform.png")]
+
+
+def save_stack_visualizations(handle: _lib.Handle, stack: np.ndarray, vis_dir, hessian: str = "gaussian_derivatives"):
+    """The two image dumps of the reference's Z-stack branch (compute_branches.py:228-229 original_image.png = the max
+    projection, :303 vesselness_image.png) for one stack, through the same GPU path.  Returns the written paths."""
+    import os
+    from pathlib import Path
+    from PIL import Image
+    from . import sato
+
+    vis_dir = Path(vis_dir)
+    vis_dir.mkdir(parents=True, exist_ok=True)
+    field = sato.stack_field(handle, stack, DOWNSAMPLE_WIDTH, hessian)
+
+    def save_vis(a, name):
+        a = np.asarray(a, np.float64)
+        lo, hi = a.min(), a.max()
+        a = (a - lo) / (hi - lo) * 255.0 if hi != lo else np.clip(a, 0, 255)
+        file = vis_dir / name
+        stem, ext = os.path.splitext(file.name)
+        n = 1
+        while file.exists():                                # helper.get_unique_output_filepath
+            n += 1
+            file = vis_dir / f"{stem}-{n}{ext}"
+        Image.fromarray(np.rint(a).astype(np.uint8)).save(file)
+        return str(file)
+    return [save_vis(np.asarray(stack).max(0), "original_image.png"), save_vis(field, "vesselness_image.png")]

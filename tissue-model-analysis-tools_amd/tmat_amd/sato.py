@@ -168,3 +168,21 @@ def analyze_stack(handle: Handle, stack: np.ndarray, graph_thresh_1, graph_thres
                                    int(bool(remove_isolated)), int(index), C.byref(row), ptr(field) if return_field else None), "tmat_analyze_stack")
     res = (row.count, row.total_px, row.avg_px)
     return res + (field,) if return_field else res
+
+
+def field_stats(handle: Handle, field: np.ndarray, graph_thresh_1, graph_thresh_2, smoothing_window_px, min_branch_length_px,
+                max_branch_length_px=None, remove_isolated=False, index=0):
+    """tmat_field_stats: vesselness image -> (count, total_px, avg_px)"""
+    f = np.ascontiguousarray(field, np.float32)
+    row = Row()
+    check(lib().tmat_field_stats(handle.raw, ptr(f), f.shape[0], f.shape[1], float(graph_thresh_1), float(graph_thresh_2), int(smoothing_window_px),
+                                 int(min_branch_length_px), int(max_branch_length_px or 0), int(bool(remove_isolated)), int(index), C.byref(row)),
+          "tmat_field_stats")
+    return row.count, row.total_px, row.avg_px
+
+
+def stack_field(handle: Handle, stack: np.ndarray, ds_width=384, hessian="gaussian_derivatives") -> np.ndarray:
+    """compute_branches.py:247-302 for one stack: the (round(H ds_width / W), ds_width) vesselness image"""
+    a = _as_u16_stack(stack)
+    out_hw = dsamp_shape(a.shape, ds_width)
+    return vessel_field(handle, stack_prepare(handle, a, out_hw), hessian)
