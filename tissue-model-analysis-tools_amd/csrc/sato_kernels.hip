@@ -20,6 +20,7 @@
 #include "morph.h"
 #include "sato.h"
 
+#include <algorithm>
 #include <cmath>
 
 namespace tmat {
@@ -71,11 +72,100 @@ __global__ __launch_bounds__(256) void corr1d_kernel(const TI *__restrict__ in, 
     }
 }
 
+// The two fast forms for symmetric / antisymmetric kernels.  Both keep the accumulation order of every output exactly as above.
+//
+// Strided axis (inner > 1; lanes = neighbouring columns, so every load is one coalesced row segment): a thread owns CK
+// consecutive outputs of its column and slides two register windows over the line -- x[l0 + k + j] and x[l0 + k - j],
+// k < CK -- so each tap step costs two loads for CK outputs instead of 2 CK.  The windows are circular buffers whose slot
+// arithmetic is static once the tap loop is unrolled by CK.
+template <typename TI, typename TO, int CK>
+__global__ __launch_bounds__(256) void corr1d_col_kernel(const TI *__restrict__ in, TO *__restrict__ out, size_t total_threads, int L, int inner, int groups,
+                                                         const double *__restrict__ w, int r, int sym, int mode)
+{
+    FLAT_LOOP(p, total_threads) {
+        const size_t og = p / (size_t)inner;
+        const int i = (int)(p - og * inner);
+        const size_t o = og / (size_t)groups;
+        const int l0 = (int)(og - o * groups) * CK;
+        const TI *line = in + o * (size_t)L * inner + i;
+        TO *oline = out + o * (size_t)L * inner + i;
+        auto at = [&](int l) { return (double)line[(size_t)ext_idx(l, L, mode) * inner]; };
+        double t[CK], lo[CK], hi[CK];
+#pragma unroll
+        for (int k = 0; k < CK; k++) {
+            t[k] = at(l0 + k) * w[r];                   // rows past the end are computed on extended data and not stored
+            lo[k] = at(l0 + k - r);                     // slot (m + k) % CK at m = 0
+            hi[k] = at(l0 + k + r);                     // slot (k - m) % CK at m = 0
+        }
+        int m = 0;
+        for (; m + CK <= r; m += CK) {
+#pragma unroll
+            for (int u = 0; u < CK; u++) {
+                const double wj = w[m + u];
+#pragma unroll
+                for (int k = 0; k < CK; k++) {
+                    const double a = lo[(u + k) % CK], b = hi[(k - u + CK) % CK];
+                    t[k] = t[k] + (sym > 0 ? a + b : a - b) * wj;
+                }
+                // step m + u -> m + u + 1: the low window gains x[l0 - r + (m + u) + CK], the high window x[l0 + r - (m + u) - 1]
+                lo[u % CK] = at(l0 - r + m + u + CK);
+                hi[(CK - 1 - u) % CK] = at(l0 + r - m - u - 1);
+            }
+        }
+        for (; m < r; m++) {                            // fewer than CK taps left: plain loads
+            const double wj = w[m];
+#pragma unroll
+            for (int k = 0; k < CK; k++) {
+                const double a = at(l0 + k - r + m), b = at(l0 + k + r - m);
+                t[k] = t[k] + (sym > 0 ? a + b : a - b) * wj;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CK; k++) if (l0 + k < L) oline[(size_t)(l0 + k) * inner] = (TO)t[k];
+    }
+}
+
+// Contiguous axis (inner == 1): a block stages one segment of a line plus its 2 r halo in LDS as f64 (boundary extension and
+// the f32 -> f64 conversion happen once, at the fill), then every thread accumulates its outputs from LDS.
+#define CORR_SEG 512
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void corr1d_row_kernel(const TI *__restrict__ in, TO *__restrict__ out, int L, int segs, const double *__restrict__ w, int r,
+                                                         int sym, int mode)
+{
+    extern __shared__ double s_line[];
+    const size_t lineno = blockIdx.x / segs;
+    const int seg0 = (int)(blockIdx.x - lineno * segs) * CORR_SEG;
+    const TI *line = in + lineno * (size_t)L;
+    const int nseg = min(CORR_SEG, L - seg0);
+    for (int q = threadIdx.x; q < nseg + 2 * r; q += 256) s_line[q] = (double)line[ext_idx(seg0 - r + q, L, mode)];
+    __syncthreads();
+    for (int q = threadIdx.x; q < nseg; q += 256) {
+        const double *c = s_line + q + r;
+        double t = c[0] * w[r];
+        if (sym > 0) for (int j = -r; j < 0; j++) t = t + (c[j] + c[-j]) * w[r + j];
+        else for (int j = -r; j < 0; j++) t = t + (c[j] - c[-j]) * w[r + j];
+        out[lineno * (size_t)L + seg0 + q] = (TO)t;
+    }
+}
+
 template <typename TI, typename TO>
 static void launch_corr1d_t(const TI *in, TO *out, size_t outer, int L, int inner, const double *w, int r, int sym, int mode, hipStream_t s)
 {
     const size_t total = outer * (size_t)L * inner;
     if (!total) return;
+    if (sym != 0 && inner == 1 && (size_t)(CORR_SEG + 2 * r) * sizeof(double) <= 60 * 1024) {
+        const int segs = (L + CORR_SEG - 1) / CORR_SEG;
+        hipLaunchKernelGGL((corr1d_row_kernel<TI, TO>), dim3((unsigned)(outer * segs)), dim3(256), (size_t)(CORR_SEG + 2 * r) * sizeof(double), s, in, out, L,
+                           segs, w, r, sym, mode);
+        return;
+    }
+    if (sym != 0 && inner > 1 && r >= 4) {
+        constexpr int CK = 8;
+        const int groups = (L + CK - 1) / CK;
+        const size_t threads = outer * (size_t)groups * inner;
+        hipLaunchKernelGGL((corr1d_col_kernel<TI, TO, CK>), grid_for(threads), dim3(256), 0, s, in, out, threads, L, inner, groups, w, r, sym, mode);
+        return;
+    }
     hipLaunchKernelGGL((corr1d_kernel<TI, TO>), grid_for(total), dim3(256), 0, s, in, out, total, L, inner, w, r, sym, mode);
 }
 void launch_corr1d_f32(const float *in, float *out, size_t outer, int L, int inner, const double *w, int r, int sym, int mode, hipStream_t s) { launch_corr1d_t(in, out, outer, L, inner, w, r, sym, mode, s); }
@@ -104,7 +194,13 @@ __global__ __launch_bounds__(256) void minmax_all_kernel(const T *__restrict__ x
         const unsigned long long l2 = __shfl_down(lo, o), h2 = __shfl_down(hi, o);
         lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
     }
-    if ((threadIdx.x & 63) == 0) { atomicMin(&mm[0], lo); atomicMax(&mm[1], hi); }
+    __shared__ unsigned long long slo[4], shi[4];
+    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {         // one pair of atomics per block (the grid is capped: a few thousand in all)
+        for (int i = 1; i < 4; i++) { lo = slo[i] < lo ? slo[i] : lo; hi = shi[i] > hi ? shi[i] : hi; }
+        atomicMin(&mm[0], lo); atomicMax(&mm[1], hi);
+    }
 }
 __global__ void minmax_decode_kernel(const unsigned long long *mm, double *out) { out[0] = key_f64(mm[0]); out[1] = key_f64(mm[1]); }
 
@@ -146,11 +242,12 @@ int stack_zoom_rescale_dev(const double *filtered, const uint16_t *stack_after_g
 {
     const size_t nin = (size_t)Z * H * W, nout = (size_t)Z * oh * ow;
     hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, s, mm);
-    hipLaunchKernelGGL((minmax_all_kernel<uint16_t>), grid_for(nin), dim3(256), 0, s, stack_after_gauss, nin, mm);
+    const dim3 rgrid_in((unsigned)std::min<size_t>(2048, (nin + 255) / 256)), rgrid_out((unsigned)std::min<size_t>(2048, (nout + 255) / 256));
+    hipLaunchKernelGGL((minmax_all_kernel<uint16_t>), rgrid_in, dim3(256), 0, s, stack_after_gauss, nin, mm);
     hipLaunchKernelGGL(minmax_decode_kernel, dim3(1), dim3(1), 0, s, mm, lohi);
     hipLaunchKernelGGL(zoom_stack_kernel, grid_for(nout), dim3(256), 0, s, filtered, H, W, oh, ow, r0, r1, wr0, wr1, c0, c1, wc0, wc1, lohi, zoomed, nout);
     hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, s, mm);
-    hipLaunchKernelGGL((minmax_all_kernel<double>), grid_for(nout), dim3(256), 0, s, zoomed, nout, mm);
+    hipLaunchKernelGGL((minmax_all_kernel<double>), rgrid_out, dim3(256), 0, s, zoomed, nout, mm);
     hipLaunchKernelGGL(minmax_decode_kernel, dim3(1), dim3(1), 0, s, mm, lohi + 2);
     hipLaunchKernelGGL(rescale01_f64_kernel, grid_for(nout), dim3(256), 0, s, zoomed, nout, lohi + 2, vol);
     return hipGetLastError() == hipSuccess ? 0 : -2;
