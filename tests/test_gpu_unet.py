@@ -75,3 +75,23 @@ def test_large_launch_race_screen(weights):
             assert bad.size == 0, f"rep {rep}: {bad.size} of {n} patches differ (first {bad[:8]})"
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("env", [{"TMAT_FUSED_POOL": "0"}, {"TMAT_FUSED_SEP": "0"}])
+def test_unfused_down_path_variants_give_the_same_bits(weights, env, monkeypatch):
+    """the down path has three forms -- separate depthwise / pointwise / pool kernels, fused depthwise->pointwise, and that with
+    the max-pool + residual add behind it (the default) -- selected per handle at creation; all must equal the oracle"""
+    from oracle import unet as ou
+    from tmat_amd import synth, _lib
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rs = np.random.RandomState(11)
+    x = rs.uniform(0, 1, (3, 320, 320)).astype(np.float32)
+    x[2, 100:220, 100:220] = 0.0
+    h = _lib.Handle(synth.pack_weights(weights), 0, 8)
+    try:
+        got = h.unet_predict(x)
+    finally:
+        h.close()
+    ref = ou.forward_exact(weights, x)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))

@@ -79,19 +79,28 @@ struct SepArgs {
     const float *pw;      // pointwise weights [Cin][Cout] (the Keras layout)
     const float *scale, *shift;
     int relu_out;
-    float *out;           // (N, H, W, Cout)
+    float *out;           // (N, H, W, Cout); POOL: (N, H/2, W/2, Cout) = pooled + resid, except row 7 / column 7 of every tile, which are
+                          // left as partial maxima for pool_fix_add_kernel
+    const float *resid;   // POOL only: (N, H/2, W/2, Cout)
+    // POOL only: what the tiles above / left of this one need from it (pool_fix_add_kernel)
+    float *strip_h;       // [tile][8][Cout]: row 0 of the tile, max over x in {2 px, 2 px + 1, 2 px + 2} (px = 7: without x = 16)
+    float *strip_v;       // [tile][8][Cout]: column 0 of the tile, max over y in {2 py, 2 py + 1, 2 py + 2} (py = 7: without y = 16)
+    float *corner;        // [tile][Cout]:   pixel (0, 0) of the tile
 };
 
 // PIXMAP: MFMA row rho (0..31) of wave w -> tile pixel (2w + yl, x)
 __device__ __forceinline__ int pixmap_y(int r) { return ((r >= 4 && r < 12) || (r >= 16 && r < 20) || r >= 28) ? 1 : 0; }
 __device__ __forceinline__ int pixmap_x(int r) { return r < 4 ? r : r < 12 ? r - 4 : r < 16 ? r - 8 : r < 20 ? r - 8 : r < 28 ? r - 12 : r - 16; }
 
-template <bool RELU_IN>
+template <bool RELU_IN, bool POOL>
 __global__ __launch_bounds__(512, SEP_WPS) void sepconv_mfma_kernel(SepArgs a, int nMt, int nNt, int G)
 {
     __shared__ __attribute__((aligned(16))) float stage0[SEP_STAGE_FLOATS];
     __shared__ __attribute__((aligned(16))) float stage1[SEP_STAGE_FLOATS];
     __shared__ __attribute__((aligned(16))) float stage2[SEP_STAGE_FLOATS];
+    // POOL: what wave w + 1 hands to wave w at the end of a tile -- its upper row pooled along x (8 values) and that row's
+    // first pixel, per output channel.  Its own object: the ring stages have LDS-DMA in flight around the epilogue.
+    __shared__ float xch[POOL ? 8 * 9 * 128 : 1];
 
     // Persistent ranges: blocks b and b + 8 share an XCD; give every XCD a contiguous super-range of the (pixel tile,
     // channel tile) pairs and every workgroup a contiguous piece of it, so the overlapping halos of neighbouring tiles
@@ -233,6 +242,92 @@ __global__ __launch_bounds__(512, SEP_WPS) void sepconv_mfma_kernel(SepArgs a, i
         }
     };
 
+    // ---- POOL epilogue: MaxPooling2D(3, strides 2, "same") of the tile (models.py:138; TF pads after, so output (py, px)
+    // covers rows 2 py .. 2 py + 2, columns 2 px .. 2 px + 2) straight from the accumulators.  A wave holds tile rows
+    // y0 = 2 w, y1 = 2 w + 1; per lane and channel group the 16 registers are 4 x-quads, and for every quad one half
+    // wave holds the y0 pixels, the other half the y1 pixels (PIXMAP), so one cross-half exchange gives a half wave both
+    // rows of "its" 9 columns 8 h .. 8 h + 8.  Row 2 w + 2 comes from wave w + 1 through LDS (already pooled along x).
+    // What lies in the next tile (row 16, column 16) is missing here: the pooled values of row 7 / column 7 are partial,
+    // and the tile's own row 0 / column 0 / corner go to the strips for pool_fix_add_kernel to finish its neighbours.
+    auto store_tile_pool = [&](int jj) {
+        const int mt = jj / nNt, nt = jj - mt * nNt;
+        const int n = mt / TPP, tr = mt - n * TPP;
+        const int ty = tr / TW, tx = tr - ty * TW;
+        const int n0 = nt * 128;
+        const int Wp = a.W >> 1;
+        const size_t T = (size_t)n * TPP + tr;
+        float hm[4][4], vs[4];
+        constexpr float NEG = -__builtin_inff();
+#pragma unroll
+        for (int jn = 0; jn < 4; jn++) {
+            const float sc = a.scale[n0 + jn * 32 + r], sh = a.shift[n0 + jn * 32 + r];
+            float v[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                v[e] = fmaf(acc[jn][e], sc, sh);
+                if (a.relu_out) v[e] = fmaxf(v[e], 0.f);
+                acc[jn][e] = 0.f;
+            }
+            // columns 8 h + k, k = 0..7: own register 8 h + k; the other half's register of the same index holds the other row
+            float y0[9], y1[9];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float own = h ? v[8 + k] : v[k];
+                const float oth = __shfl_xor(h ? v[k] : v[8 + k], 32);      // the other half sends what this one lacks
+                y0[k] = k < 4 ? own : oth;                                   // quads 0, 2: this half holds y0; quads 1, 3: y1
+                y1[k] = k < 4 ? oth : own;
+            }
+            {   // column 8 h + 8: x = 8 for h = 0 (register 8: this half holds its y1, the other half its y0), none for h = 1
+                const float o8 = __shfl_xor(v[8], 32);
+                y0[8] = h ? NEG : o8;
+                y1[8] = h ? NEG : v[8];
+            }
+            float m01[9], h0[4];
+#pragma unroll
+            for (int k = 0; k < 9; k++) m01[k] = fmaxf(y0[k], y1[k]);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {                   // pooled column 4 h + q
+                hm[jn][q] = fmaxf(fmaxf(m01[2 * q], m01[2 * q + 1]), m01[2 * q + 2]);
+                h0[q] = fmaxf(fmaxf(y0[2 * q], y0[2 * q + 1]), y0[2 * q + 2]);
+                xch[(wave * 9 + 4 * h + q) * 128 + jn * 32 + r] = h0[q];
+                if (wave == 0) a.strip_h[(T * 8 + 4 * h + q) * a.Cout + n0 + jn * 32 + r] = h0[q];
+            }
+            vs[jn] = m01[0];                                // meaningful in half 0 (column 0)
+            if (h == 0) {
+                xch[(wave * 9 + 8) * 128 + jn * 32 + r] = y0[0];
+                if (wave == 0) a.corner[T * a.Cout + n0 + jn * 32 + r] = y0[0];
+            }
+        }
+        const size_t pix = (((size_t)n * (a.H >> 1) + ty * 8 + wave) * Wp + tx * 8 + 4 * h) * a.Cout + n0 + r;
+        float *pbase = a.out + pix;
+        const float *rbase = a.resid + pix;
+        float rv[4][4];
+        if (wave < 7) {             // pooled row 7 is finished (and gets its residual) in pool_fix_add_kernel
+#pragma unroll
+            for (int jn = 0; jn < 4; jn++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) rv[jn][q] = (q < 3 || h == 0) ? rbase[(size_t)q * a.Cout + jn * 32] : 0.f;     // so is column 7
+        }
+        __syncthreads();
+#pragma unroll
+        for (int jn = 0; jn < 4; jn++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float pv = hm[jn][q];
+                if (wave < 7) {
+                    pv = fmaxf(pv, xch[((wave + 1) * 9 + 4 * h + q) * 128 + jn * 32 + r]);
+                    if (q < 3 || h == 0) pv = pv + rv[jn][q];
+                }
+                pbase[(size_t)q * a.Cout + jn * 32] = pv;
+            }
+            if (h == 0) {
+                float cv = vs[jn];
+                if (wave < 7) cv = fmaxf(cv, xch[((wave + 1) * 9 + 8) * 128 + jn * 32 + r]);
+                a.strip_v[(T * 8 + wave) * a.Cout + n0 + jn * 32 + r] = cv;
+            }
+        }
+    };
+
 #define SEP_STEP(SA, SB, SC)                                                                                    \
     {                                                                                                           \
         const char *sa = reinterpret_cast<const char *>(SA);                                                    \
@@ -251,7 +346,7 @@ __global__ __launch_bounds__(512, SEP_WPS) void sepconv_mfma_kernel(SepArgs a, i
         /* seg 7 */ SEP_RB(sb, bqa, 0, 0) SEP_MM(a1.w, bqb) SEP_PIN()                                           \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
         __syncthreads();                                                                                        \
-        if (++cc == nchunks) { cc = 0; store_tile(cj); cj++; }                                                  \
+        if (++cc == nchunks) { cc = 0; if (POOL) store_tile_pool(cj); else store_tile(cj); cj++; }                                                  \
         if (--left == 0) break;                                                                                 \
     }
 
@@ -296,6 +391,18 @@ bool sepconv_supported(int H, int W, int Cin, int Cout)
            (long long)H * W * Cin * 4 < 0x7fffffffLL && (long long)16 * W * Cout * 4 < 0x7fffffffLL;
 }
 
+static int sep_cus()
+{
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 8) n_cu = 256;
+        else n_cu = prop.multiProcessorCount;
+    }
+    return n_cu;
+}
+
 // in (N, H, W, Cin) -> out (N, H, W, Cout): depthwise 3x3 (taps dwq [Cin/16][9][16], optional ReLU on load) ->
 // pointwise (pw [Cin][Cout]) -> fmaf(acc, scale, shift) -> optional ReLU
 bool launch_sepconv(const float *in, int N, int H, int W, int Cin, int relu_in, const float *dwq, const float *pw, int Cout,
@@ -305,20 +412,75 @@ bool launch_sepconv(const float *in, int N, int H, int W, int Cin, int relu_in, 
         set_error("launch_sepconv: unsupported shape");
         return false;
     }
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 8) n_cu = 256;
-        else n_cu = prop.multiProcessorCount;
-    }
-    SepArgs a{in, N, H, W, Cin, Cout, dwq, pw, scale, shift, relu_out, out};
+    SepArgs a{in, N, H, W, Cin, Cout, dwq, pw, scale, shift, relu_out, out, nullptr, nullptr, nullptr, nullptr};
     const int nMt = N * (H / 16) * (W / 16), nNt = Cout / 128;
-    const int G = (n_cu / 8) * 8;                 // one persistent workgroup per CU (93 KiB of LDS each)
+    const int G = (sep_cus() / 8) * 8;            // one persistent workgroup per CU (93 KiB of LDS each)
     if (relu_in)
-        hipLaunchKernelGGL(sepconv_mfma_kernel<true>, dim3(G), dim3(512), 0, s, a, nMt, nNt, G);
+        hipLaunchKernelGGL((sepconv_mfma_kernel<true, false>), dim3(G), dim3(512), 0, s, a, nMt, nNt, G);
     else
-        hipLaunchKernelGGL(sepconv_mfma_kernel<false>, dim3(G), dim3(512), 0, s, a, nMt, nNt, G);
+        hipLaunchKernelGGL((sepconv_mfma_kernel<false, false>), dim3(G), dim3(512), 0, s, a, nMt, nNt, G);
+    return true;
+}
+
+// Finishes the pooling the separable convolution started in its epilogue: the partial pooled values of a tile's last row /
+// column take the missing row 16 / column 16 from the strips of the tile below / to the right (nothing at the patch border:
+// TF pads with -inf) and get their residual, in place.  One thread = 4 channels of one of the 15 boundary pixels of a tile.
+__global__ __launch_bounds__(256) void pool_fix_add_kernel(float *__restrict__ out, const float *__restrict__ strip_h, const float *__restrict__ strip_v,
+                                                           const float *__restrict__ corner, const float *__restrict__ resid, int Hp, int Wp, int C,
+                                                           int c4shift, int total)
+{
+    const int n = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int cq = e & ((1 << c4shift) - 1);
+    const int bp = e >> c4shift;                     // boundary pixel: tile * 15 + k
+    const int tile = bp / 15, k = bp - tile * 15;
+    const int TH = Hp >> 3, TW = Wp >> 3, ty = tile / TW, tx = tile - ty * TW;
+    const int pl = k < 8 ? 7 : k - 8, ql = k < 8 ? k : 7;
+    const size_t o = (((size_t)n * Hp + ty * 8 + pl) * Wp + tx * 8 + ql) * C + cq * 4;
+    float4 m = *reinterpret_cast<const float4 *>(out + o);
+    auto take = [&](const float *src) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + cq * 4);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    };
+    const bool below = pl == 7 && ty + 1 < TH, right = ql == 7 && tx + 1 < TW;
+    if (below) take(strip_h + ((((size_t)n * TH + ty + 1) * TW + tx) * 8 + ql) * C);
+    if (right) take(strip_v + ((((size_t)n * TH + ty) * TW + tx + 1) * 8 + pl) * C);
+    if (below && right) take(corner + (((size_t)n * TH + ty + 1) * TW + tx + 1) * C);
+    const float4 rv = *reinterpret_cast<const float4 *>(resid + o);
+    m.x = m.x + rv.x; m.y = m.y + rv.y; m.z = m.z + rv.z; m.w = m.w + rv.w;
+    *reinterpret_cast<float4 *>(out + o) = m;
+}
+
+size_t sepconv_pool_scratch_floats(int N, int H, int W, int Cout)
+{
+    return (size_t)N * (H / 16) * (W / 16) * 17 * Cout;          // strips: 8 + 8 + 1 pixels per tile
+}
+
+// The second separable convolution of a down block with MaxPooling2D(3, 2, "same") and the residual add fused behind it
+// (models.py:134-144): in (N, H, W, Cin) -> out (N, H/2, W/2, Cout) = maxpool(bn(sepconv(in))) + resid.  `scratch` holds
+// sepconv_pool_scratch_floats(...) floats (the tile-edge strips); the full-resolution tensor is never written.
+bool launch_sepconv_pool(const float *in, int N, int H, int W, int Cin, int relu_in, const float *dwq, const float *pw, int Cout,
+                         const float *scale, const float *shift, int relu_out, float *scratch, const float *resid, float *out, hipStream_t s)
+{
+    if (!sepconv_supported(H, W, Cin, Cout) || N <= 0 || (long long)N * (H / 16) * (W / 16) * (Cout / 128) > 0x3fffffffLL || Cout % 4) {
+        set_error("launch_sepconv_pool: unsupported shape");
+        return false;
+    }
+    const size_t tiles = (size_t)N * (H / 16) * (W / 16);
+    float *sh = scratch, *sv = sh + tiles * 8 * Cout, *co = sv + tiles * 8 * Cout;
+    SepArgs a{in, N, H, W, Cin, Cout, dwq, pw, scale, shift, relu_out, out, resid, sh, sv, co};
+    const int nMt = N * (H / 16) * (W / 16), nNt = Cout / 128;
+    const int G = (sep_cus() / 8) * 8;
+    if (relu_in)
+        hipLaunchKernelGGL((sepconv_mfma_kernel<true, true>), dim3(G), dim3(512), 0, s, a, nMt, nNt, G);
+    else
+        hipLaunchKernelGGL((sepconv_mfma_kernel<false, true>), dim3(G), dim3(512), 0, s, a, nMt, nNt, G);
+    int c4shift = 0;
+    while ((1 << c4shift) < Cout / 4) c4shift++;
+    if ((1 << c4shift) != Cout / 4) { set_error("launch_sepconv_pool: Cout / 4 must be a power of two"); return false; }
+    const int total = (H / 16) * (W / 16) * 15 * (Cout / 4);
+    hipLaunchKernelGGL(pool_fix_add_kernel, dim3((total + 255) / 256, N), dim3(256), 0, s, out, sh, sv, co, resid, H / 2, W / 2, Cout, c4shift, total);
     return true;
 }
 

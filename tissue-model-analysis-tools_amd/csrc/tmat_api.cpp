@@ -279,13 +279,20 @@ int unet_down_dev(Ctx *c, const float *X, int n, float *dout, hipStream_t s)
         // prev = b0 (n, H, H, cin)
         if (c->fused_sep && d.dwq[0] && d.dwq[1] && sepconv_supported(H, H, d.cin, d.cout) && sepconv_supported(H, H, d.cout, d.cout)) {
             // stem output is already >= 0, so ReLU on load is the identity in the first block
-            if (!launch_sepconv(b0, n, H, H, d.cin, bi > 0, d.dwq[0], d.pwT[0], d.cout, d.scale[0], d.shift[0], 1, b2, s) ||
-                !launch_sepconv(b2, n, H, H, d.cout, 0, d.dwq[1], d.pwT[1], d.cout, d.scale[1], d.shift[1], 0, b3, s)) return TMAT_E_ARG;
+            if (!launch_sepconv(b0, n, H, H, d.cin, bi > 0, d.dwq[0], d.pwT[0], d.cout, d.scale[0], d.shift[0], 1, b2, s)) return TMAT_E_ARG;
             ConvArgs r{};
             r.in = b0; r.N = n; r.h = H; r.w = H; r.Cin = d.cin; r.ksize = 1; r.stride = 2; r.W = d.res_w; r.Cout = d.cout;
             r.scale = nullptr; r.shift = d.res_b; r.out = b1;
             if (!conv(c, r, s)) return TMAT_E_ARG;
-            launch_maxpool_add(b3, n, H, H, d.cout, b1, bi + 1 == c->down.size() ? dout : b0, s);
+            float *nxt = bi + 1 == c->down.size() ? dout : b0;
+            if (c->fused_pool && ((d.cout / 4) & (d.cout / 4 - 1)) == 0) {
+                // pooling + residual add behind the second separable convolution: its full-resolution output never reaches HBM
+                // (b3 only holds the tile-edge strips, 17 of a tile's 256 pixels)
+                if (!launch_sepconv_pool(b2, n, H, H, d.cout, 0, d.dwq[1], d.pwT[1], d.cout, d.scale[1], d.shift[1], 0, b3, b1, nxt, s)) return TMAT_E_ARG;
+            } else {
+                if (!launch_sepconv(b2, n, H, H, d.cout, 0, d.dwq[1], d.pwT[1], d.cout, d.scale[1], d.shift[1], 0, b3, s)) return TMAT_E_ARG;
+                launch_maxpool_add(b3, n, H, H, d.cout, b1, nxt, s);
+            }
             H /= 2;
             continue;
         }
@@ -453,6 +460,7 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
     c->patch = patch;
     c->max_patches = max_patches > 0 ? max_patches : 400;
     if (const char *e = getenv("TMAT_FUSED_SEP")) c->fused_sep = atoi(e) != 0;
+    if (const char *e = getenv("TMAT_FUSED_POOL")) c->fused_pool = atoi(e) != 0;
     if (const char *e = getenv("TMAT_DMT_DEVICE")) c->dmt_device = atoi(e) != 0;
     if (const char *e = getenv("TMAT_THIN_DEVICE")) c->thin_device = atoi(e) != 0;
     // the UNet stream gets the highest priority, the side stream of the post-processing stages (thinning rounds, finish,

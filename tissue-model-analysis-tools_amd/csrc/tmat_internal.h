@@ -33,6 +33,10 @@ bool launch_conv(const ConvArgs &a, hipStream_t s);
 bool sepconv_supported(int H, int W, int Cin, int Cout);
 bool launch_sepconv(const float *in, int N, int H, int W, int Cin, int relu_in, const float *dwq, const float *pw, int Cout,
                     const float *scale, const float *shift, int relu_out, float *out, hipStream_t s);
+// the same with MaxPooling2D(3, 2, "same") + residual add fused behind it: out (N, H/2, W/2, Cout); scratch: sepconv_pool_scratch_floats
+size_t sepconv_pool_scratch_floats(int N, int H, int W, int Cout);
+bool launch_sepconv_pool(const float *in, int N, int H, int W, int Cin, int relu_in, const float *dwq, const float *pw, int Cout,
+                         const float *scale, const float *shift, int relu_out, float *scratch, const float *resid, float *out, hipStream_t s);
 void launch_dwconv(const float *in, int N, int H, int W, int C, int relu_in, const float *Wd, float *out, hipStream_t s);
 void launch_stem(const float *x, int N, int H, int W, const float *Ws, int Cout, const float *scale,
                  const float *shift, float *out, hipStream_t s);

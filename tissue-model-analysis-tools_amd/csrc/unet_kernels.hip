@@ -288,6 +288,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
 #undef TMAT_DMA_B
 #undef TMAT_ISSUE_CHUNK
 
+#ifdef TMAT_ABL_NOEPI      // timing ablation only (results are wrong): one store per lane instead of the epilogue
+    { float sacc = 0.f;
+      for (int i = 0; i < TM; i++) for (int jn = 0; jn < TN; jn++) for (int r = 0; r < 16; r++) sacc += acc[i][jn][r];
+      if (m0 + t < M) a.out[(size_t)(m0 + t) * a.Cout + n0] = sacc;
+      return; }
+#endif
     // epilogue: accumulators -> LDS tile [128][BN] (C/D layout: col = lane & 31 is the output channel,
     // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) the pixel) -> BN fold / bias, residual, ReLU on float4 rows ->
     // 16-byte coalesced stores (one wave writes 1 KiB contiguous).

@@ -48,38 +48,36 @@ def gaussian_kernel1d(sigma: float, order: int, radius: int) -> np.ndarray:
     return np.ascontiguousarray((q * phi_x)[::-1], np.float64)
 
 
-def set_gaussian_table(handle: Handle, sigma: float, order: int, truncate: float):
+def ensure_gaussian_table(handle: Handle, sigma: float, order: int, truncate: float):
+    """register scipy's table for (sigma, order, radius = int(truncate sigma + 0.5)) on the handle, once"""
+    done = getattr(handle, "_gauss_done", None)
+    if done is None:
+        done = handle._gauss_done = set()
     radius = int(truncate * float(sigma) + 0.5)
+    key = (float(sigma), int(order), radius)
+    if key in done:
+        return
     w = gaussian_kernel1d(float(sigma), order, radius)
     check(lib().tmat_set_gaussian_table(handle.raw, float(sigma), order, radius, ptr(w)), "tmat_set_gaussian_table")
+    done.add(key)
 
 
 def install_gaussian_tables(handle: Handle, stack_hw=None, out_hw=None, sigmas=SATO_SIGMAS):
     """register every table the branch uses: sigma 1 and 2 (truncate 4), the Sato scales in both Hessian forms, and the
     anti-aliasing sigmas of the resize from stack_hw to out_hw"""
-    done = getattr(handle, "_gauss_done", None)
-    if done is None:
-        done = handle._gauss_done = set()
-
-    def put(sigma, order, truncate):
-        key = (float(sigma), order, float(truncate))
-        if key not in done:
-            set_gaussian_table(handle, sigma, order, truncate)
-            done.add(key)
-
-    put(1.0, 0, 4.0)
-    put(2.0, 0, 4.0)
+    ensure_gaussian_table(handle, 1.0, 0, 4.0)
+    ensure_gaussian_table(handle, 2.0, 0, 4.0)
     sq1_2 = 1 / math.sqrt(2)
     for s in sigmas:
-        put(float(s), 0, 4.0)                                   # gradient form
-        tr = 8.0 if s > 1 else 100.0                            # corner.py:_hessian_matrix_with_gaussian
-        put(sq1_2 * s, 0, tr)
-        put(sq1_2 * s, 1, tr)
+        ensure_gaussian_table(handle, float(s), 0, 4.0)          # gradient form
+        tr = 8.0 if s > 1 else 100.0                             # corner.py:_hessian_matrix_with_gaussian
+        ensure_gaussian_table(handle, sq1_2 * s, 0, tr)
+        ensure_gaussian_table(handle, sq1_2 * s, 1, tr)
     if stack_hw is not None and out_hw is not None:
         for n_in, n_out in zip(stack_hw, out_hw):
             sg = max(0.0, (n_in / n_out - 1) / 2)
             if sg > 1e-15:
-                put(sg, 0, 4.0)
+                ensure_gaussian_table(handle, sg, 0, 4.0)
 
 
 def gaussian(handle: Handle, x: np.ndarray, sigma=1.0, mode=NEAREST) -> np.ndarray:
@@ -87,10 +85,7 @@ def gaussian(handle: Handle, x: np.ndarray, sigma=1.0, mode=NEAREST) -> np.ndarr
     x = np.ascontiguousarray(x, np.float32)
     if x.ndim not in (2, 3):
         raise ValueError("gaussian: 2-D or 3-D float32 input")
-    put = getattr(handle, "_gauss_done", None)
-    if put is None or (float(sigma), 0, 4.0) not in put:
-        install_gaussian_tables(handle, sigmas=())
-        set_gaussian_table(handle, sigma, 0, 4.0)
+    ensure_gaussian_table(handle, sigma, 0, 4.0)
     d = (1,) + x.shape if x.ndim == 2 else x.shape
     out = np.empty_like(x)
     check(lib().tmat_gaussian_f32(handle.raw, ptr(x), d[0], d[1], d[2], float(sigma), int(mode), ptr(out)), "tmat_gaussian_f32")
