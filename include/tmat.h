@@ -249,6 +249,24 @@ int tmat_field_stats(tmat_handle h, const float *field, int fh, int fw, float gr
                      int smoothing_window_px, int min_branch_length_px, int max_branch_length_px, int remove_isolated,
                      int64_t index, tmat_row *row);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Cell-area tool: reference scripts/compute_cell_area.py:29-87, 164-178 and
+ * fl_tissue_model_tools/preprocessing.py:44-93 (csrc/cellarea_kernels.hip).  A handle from tmat_create_plain is enough.
+ * --------------------------------------------------------------------------------------------------------------- */
+
+/*
+ * For n uint16 images (n, H, W) (Z stacks: project first, tmat_zproj_batch method max): cv2.resize to (out_h, out_w)
+ * with bilinear interpolation (compute_cell_area.py:57 passes INTER_AREA in the position of `dst`, so the default
+ * interpolation applies; out_h = out_w = 0: no resize), rescale_intensity to 0..1 as float32 (:79),
+ * preprocessing.exec_threshold (:44-93: two-component gaussian mixture of the pixel intensities -- fitted here to the
+ * intensity histogram, from the optimal 2-means partition, with scikit-learn's EM update and stopping rule -- and the
+ * threshold foreground mean + sd_coef * foreground sd), compute_area_prop (:164-178).
+ * area: n fractions of pixels kept.  thresholded (nullable): (n, out_h, out_w) u8, 255 where kept (:87).
+ * params (nullable): n x 9 doubles [threshold, weight0, weight1, mean0, mean1, var0, var1, EM iterations, converged].
+ */
+int tmat_cell_area_batch(tmat_handle h, const uint16_t *imgs, int n, int H, int W, int out_h, int out_w, double sd_coef,
+                         double *area, uint8_t *thresholded, double *params);
+
 /* device memory helpers so a ctypes host can stage inputs in HBM without torch */
 int tmat_dev_alloc(tmat_handle h, size_t bytes, void **dev_ptr);
 int tmat_dev_free(tmat_handle h, void *dev_ptr);

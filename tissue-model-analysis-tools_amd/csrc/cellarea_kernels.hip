@@ -1,0 +1,308 @@
+// Cell-area tool on gfx950 (reference scripts/compute_cell_area.py:29-87, 164-178 and
+// fl_tissue_model_tools/preprocessing.py:44-93): bilinear down-sampling, intensity histogram, a two-component gaussian
+// mixture fitted to the histogram (2-means initialisation + scikit-learn's EM), threshold, area fraction.
+//
+// The mixture is fitted to the HISTOGRAM, not to the pixels: the image is 16-bit, so the 262 144 pixels of a 512 x 512
+// image take at most 65 536 distinct values and every sum EM needs is a weighted sum over the bins.  One workgroup per
+// image holds its 64 bins per thread in registers; an EM iteration is two block reductions of a few doubles.  The pixel
+// kernels (resize, histogram, apply) are HBM-bound streaming passes of 0.5 - 2 MB per image: this tool is latency bound.
+// Arithmetic contract: oracle/cellarea.py (same formulas in float64; block-tree instead of sequential summation).
+#include "../../include/tmat.h"
+#include "tmat_ctx.h"
+
+#include <cmath>
+#include <vector>
+
+namespace tmat {
+
+// cv2.resize(INTER_LINEAR) of uint16 images: float32 weights, horizontal then vertical, round half to even, saturate
+__global__ __launch_bounds__(256) void resize_linear_u16_kernel(const uint16_t *__restrict__ img, int H, int W, int oh, int ow, const int *__restrict__ r0,
+                                                                const int *__restrict__ r1, const float *__restrict__ wr0, const float *__restrict__ wr1,
+                                                                const int *__restrict__ c0, const int *__restrict__ c1, const float *__restrict__ wc0,
+                                                                const float *__restrict__ wc1, uint16_t *__restrict__ out)
+{
+    const uint16_t *src = img + (size_t)blockIdx.y * H * W;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < oh * ow; p += gridDim.x * 256) {
+        const int y = p / ow, x = p - y * ow;
+        const float a = (float)src[(size_t)r0[y] * W + c0[x]] * wc0[x] + (float)src[(size_t)r0[y] * W + c1[x]] * wc1[x];
+        const float b = (float)src[(size_t)r1[y] * W + c0[x]] * wc0[x] + (float)src[(size_t)r1[y] * W + c1[x]] * wc1[x];
+        const float v = rintf(a * wr0[y] + b * wr1[y]);
+        out[(size_t)blockIdx.y * oh * ow + p] = (uint16_t)fminf(fmaxf(v, 0.f), 65535.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void hist_u16_kernel(const uint16_t *__restrict__ img, int npx, unsigned *__restrict__ hist)
+{
+    const uint16_t *src = img + (size_t)blockIdx.y * npx;
+    unsigned *h = hist + (size_t)blockIdx.y * 65536;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npx; p += gridDim.x * 256) atomicAdd(&h[src[p]], 1u);
+}
+
+// ---- block reductions over 1024 threads (16 waves) ----
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *scratch /* 16 * NV */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; i++)
+        for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_down(v[i], o);
+    __syncthreads();                                 // scratch may still be read from the previous reduction
+    if (lane == 0)
+        for (int i = 0; i < NV; i++) scratch[wave * NV + i] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        double t = 0.0;
+        for (int w = 0; w < 16; w++) t += scratch[w * NV + i];
+        v[i] = t;
+    }
+}
+
+constexpr int GMM_BINS_PER_THREAD = 64;
+constexpr double GMM_REG_COVAR = 1e-6, GMM_TOL = 1e-3;
+constexpr int GMM_MAX_ITER = 100;
+
+// params out per image: [0] threshold, [1..2] weights, [3..4] means, [5..6] variances, [7] iterations, [8] converged, [9] lo, [10] hi
+__global__ __launch_bounds__(1024) void gmm_hist_kernel(const unsigned *__restrict__ hist, double sd_coef, double *__restrict__ params)
+{
+    __shared__ double scratch[16 * 6];
+    __shared__ long long s_n[16], s_s[16];
+    __shared__ double s_best[16];
+    __shared__ int s_bestk[16];
+    __shared__ int s_lo, s_hi;
+    const unsigned *h = hist + (size_t)blockIdx.x * 65536;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int b0 = t * GMM_BINS_PER_THREAD;
+    unsigned cnt[GMM_BINS_PER_THREAD];
+    long long n_t = 0, s_t = 0;
+    int lo_t = 65536, hi_t = -1;
+#pragma unroll
+    for (int i = 0; i < GMM_BINS_PER_THREAD; i++) {
+        cnt[i] = h[b0 + i];
+        n_t += cnt[i];
+        s_t += (long long)cnt[i] * (b0 + i);
+        if (cnt[i]) { lo_t = lo_t < b0 + i ? lo_t : b0 + i; hi_t = b0 + i; }
+    }
+    // lowest / highest occupied level (the image min / max of rescale_intensity)
+    for (int o = 32; o > 0; o >>= 1) { const int l2 = __shfl_down(lo_t, o), h2 = __shfl_down(hi_t, o); lo_t = l2 < lo_t ? l2 : lo_t; hi_t = h2 > hi_t ? h2 : hi_t; }
+    if (t == 0) { s_lo = 65536; s_hi = -1; }
+    __syncthreads();
+    if (lane == 0) { atomicMin(&s_lo, lo_t); atomicMax(&s_hi, hi_t); }
+    // ---- 2-means optimum on the integer levels: exclusive prefix (n, s) per thread, then scan the thread's bins ----
+    long long n_w = n_t, s_w = s_t;                                       // inclusive scan inside the wave
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long n2 = __shfl_up(n_w, o), s2 = __shfl_up(s_w, o);
+        if (lane >= o) { n_w += n2; s_w += s2; }
+    }
+    if (lane == 63) { s_n[wave] = n_w; s_s[wave] = s_w; }
+    __syncthreads();
+    long long n_pre = n_w - n_t, s_pre = s_w - s_t, N = 0, S = 0;
+    for (int w = 0; w < 16; w++) { if (w < wave) { n_pre += s_n[w]; s_pre += s_s[w]; } N += s_n[w]; S += s_s[w]; }
+    double best = -INFINITY;
+    int bestk = 0;
+    {
+        long long n = n_pre, s = s_pre;
+#pragma unroll
+        for (int i = 0; i < GMM_BINS_PER_THREAD; i++) {
+            n += cnt[i]; s += (long long)cnt[i] * (b0 + i);
+            if (cnt[i] && n > 0 && n < N) {                                  // a present level that leaves both sides non-empty
+                const double sd = (double)s, rd = (double)(S - s);
+                const double between = sd * sd / (double)n + rd * rd / (double)(N - n);
+                if (between > best) { best = between; bestk = b0 + i; }
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {      // ties take the smallest level
+        const double b2 = __shfl_down(best, o); const int k2 = __shfl_down(bestk, o);
+        if (b2 > best || (b2 == best && k2 < bestk)) { best = b2; bestk = k2; }
+    }
+    if (lane == 0) { s_best[wave] = best; s_bestk[wave] = bestk; }
+    __syncthreads();
+    best = s_best[0]; bestk = s_bestk[0];
+    for (int w = 1; w < 16; w++) if (s_best[w] > best || (s_best[w] == best && s_bestk[w] < bestk)) { best = s_best[w]; bestk = s_bestk[w]; }
+    const int lo = s_lo, hi = s_hi;
+    const double dlo = (double)lo, drange = (double)hi - (double)lo;
+    // pixel value of a level: rescale_intensity(img, (0, 1)).astype(float32)
+    auto xval = [&](int level) -> double { return lo != hi ? (double)(float)(((double)level - dlo) / drange) : fmin(fmax((double)level, 0.0), 1.0); };
+    const double n_tot = (double)N, eps10 = 10.0 * 2.220446049250313e-16;
+    double w[2], mu[2], var[2];
+    // M step from the one-hot responsibilities of the 2-means partition
+    auto m_step = [&](auto resp) {
+        double a[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < GMM_BINS_PER_THREAD; i++) {
+            if (!cnt[i]) continue;
+            const double c = (double)cnt[i], x = xval(b0 + i);
+            double r0, r1;
+            resp(i, x, r0, r1);
+            a[0] += r0 * c; a[1] += r1 * c; a[2] += r0 * (c * x); a[3] += r1 * (c * x);
+        }
+        block_sum<6>(a, scratch);
+        const double nk0 = a[0] + eps10, nk1 = a[1] + eps10;
+        mu[0] = a[2] / nk0; mu[1] = a[3] / nk1;
+        double v[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < GMM_BINS_PER_THREAD; i++) {
+            if (!cnt[i]) continue;
+            const double c = (double)cnt[i], x = xval(b0 + i);
+            double r0, r1;
+            resp(i, x, r0, r1);
+            v[0] += r0 * (c * ((x - mu[0]) * (x - mu[0]))); v[1] += r1 * (c * ((x - mu[1]) * (x - mu[1])));
+        }
+        block_sum<6>(v, scratch);
+        var[0] = v[0] / nk0 + GMM_REG_COVAR; var[1] = v[1] / nk1 + GMM_REG_COVAR;
+        w[0] = nk0 / n_tot; w[1] = nk1 / n_tot;
+    };
+    m_step([&](int i, double, double &r0, double &r1) { r0 = b0 + i <= bestk ? 1.0 : 0.0; r1 = 1.0 - r0; });
+    double lower = -INFINITY;
+    int iters = 0, converged = 0;
+    const double log2pi = 1.8378770664093453;
+    for (int it = 1; it <= GMM_MAX_ITER; it++) {
+        iters = it;
+        const double prev = lower;
+        const double pc0 = 1.0 / sqrt(var[0]), pc1 = 1.0 / sqrt(var[1]);
+        const double lw0 = log(w[0]), lw1 = log(w[1]), lp0 = log(pc0), lp1 = log(pc1);
+        const double m0 = mu[0], m1 = mu[1];
+        // E step: log responsibilities per level (kept as a closure: recomputed in the M step instead of stored)
+        auto e_resp = [&](int, double x, double &r0, double &r1) {
+            const double y0 = (x - m0) * pc0, y1 = (x - m1) * pc1;
+            const double a0 = -0.5 * (log2pi + y0 * y0) + lp0 + lw0, a1 = -0.5 * (log2pi + y1 * y1) + lp1 + lw1;
+            const double mx = fmax(a0, a1);
+            const double lse = mx + log(exp(a0 - mx) + exp(a1 - mx));
+            r0 = exp(a0 - lse); r1 = exp(a1 - lse);
+        };
+        double ll[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < GMM_BINS_PER_THREAD; i++) {
+            if (!cnt[i]) continue;
+            const double x = xval(b0 + i);
+            const double y0 = (x - m0) * pc0, y1 = (x - m1) * pc1;
+            const double a0 = -0.5 * (log2pi + y0 * y0) + lp0 + lw0, a1 = -0.5 * (log2pi + y1 * y1) + lp1 + lw1;
+            const double mx = fmax(a0, a1);
+            ll[0] += (double)cnt[i] * (mx + log(exp(a0 - mx) + exp(a1 - mx)));
+        }
+        block_sum<6>(ll, scratch);
+        lower = ll[0] / n_tot;
+        m_step(e_resp);
+        if (fabs(lower - prev) < GMM_TOL) { converged = 1; break; }
+    }
+    if (t == 0) {
+        const int fg = mu[1] > mu[0] ? 1 : 0;                    // np.argmax: the first of equal means
+        double *p = params + (size_t)blockIdx.x * 11;
+        p[0] = fmin(255.0, mu[fg] + sqrt(var[fg]) * sd_coef);
+        p[1] = w[0]; p[2] = w[1]; p[3] = mu[0]; p[4] = mu[1]; p[5] = var[0]; p[6] = var[1];
+        p[7] = (double)iters; p[8] = (double)converged; p[9] = dlo; p[10] = (double)hi;
+    }
+}
+
+// gmm_masked = where(x <= thresh, 0, x); kept = gmm_masked > 0 -> 255 / 0, and the count of kept pixels
+__global__ __launch_bounds__(256) void apply_threshold_kernel(const uint16_t *__restrict__ img, int npx, const double *__restrict__ params,
+                                                              uint8_t *__restrict__ out, unsigned *__restrict__ kept)
+{
+    const double *p = params + (size_t)blockIdx.y * 11;
+    const double thresh = p[0], lo = p[9], hi = p[10], range = hi - lo;
+    const uint16_t *src = img + (size_t)blockIdx.y * npx;
+    unsigned local = 0;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < npx; q += gridDim.x * 256) {
+        const double lv = (double)src[q];
+        const double x = lo != hi ? (double)(float)((lv - lo) / range) : fmin(fmax(lv, 0.0), 1.0);
+        const bool k = !(x <= thresh) && x > 0.0;
+        if (out) out[(size_t)blockIdx.y * npx + q] = k ? 255 : 0;
+        local += k;
+    }
+    for (int o = 32; o > 0; o >>= 1) local += __shfl_down(local, o);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&kept[blockIdx.y], local);
+}
+
+// cv2's source coordinate and weights of INTER_LINEAR along one axis (float arithmetic, clamped to the image)
+static void linear_axis(int n_src, int n_dst, std::vector<int> &i0, std::vector<int> &i1, std::vector<float> &w0, std::vector<float> &w1)
+{
+    const double scale = (double)n_src / (double)n_dst;
+    i0.resize(n_dst); i1.resize(n_dst); w0.resize(n_dst); w1.resize(n_dst);
+    for (int d = 0; d < n_dst; d++) {
+        float fx = (float)(((double)d + 0.5) * scale - 0.5);
+        int sx = (int)std::floor(fx);
+        fx = fx - (float)sx;
+        if (sx < 0) { sx = 0; fx = 0.f; }
+        if (sx >= n_src - 1) { sx = n_src - 1; fx = 0.f; }
+        i0[d] = sx; i1[d] = sx + 1 < n_src ? sx + 1 : n_src - 1;
+        w0[d] = 1.0f - fx; w1[d] = fx;
+    }
+}
+
+}  // namespace tmat
+
+using namespace tmat;
+
+extern "C" int tmat_cell_area_batch(tmat_handle hd, const uint16_t *imgs, int n, int H, int W, int out_h, int out_w, double sd_coef, double *area,
+                                    uint8_t *thresholded, double *params)
+{
+    if (!hd || !imgs || !area || n < 0 || H < 1 || W < 1 || out_h < 0 || out_w < 0 || (out_h == 0) != (out_w == 0)) {
+        set_error("tmat_cell_area_batch: bad argument");
+        return TMAT_E_ARG;
+    }
+    if (n == 0) return TMAT_OK;
+    Ctx *c = (Ctx *)hd;
+    TMAT_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int oh = out_h ? out_h : H, ow = out_w ? out_w : W;
+    const size_t nin = (size_t)n * H * W, nout = (size_t)n * oh * ow;
+    uint16_t *din = nullptr, *dsm = nullptr;
+    unsigned *hist = nullptr, *kept = nullptr;
+    double *dpar = nullptr;
+    uint8_t *dthr = nullptr;
+    int *itab = nullptr;
+    float *ftab = nullptr;
+    int rc = TMAT_OK;
+    auto fail = [&](int code) { rc = code; };
+    if (!hip_ok(hipMalloc((void **)&din, nin * 2), "hipMalloc") || !hip_ok(hipMalloc((void **)&hist, (size_t)n * 65536 * 4), "hipMalloc") ||
+        !hip_ok(hipMalloc((void **)&kept, n * 4), "hipMalloc") || !hip_ok(hipMalloc((void **)&dpar, (size_t)n * 11 * 8), "hipMalloc") ||
+        (thresholded && !hip_ok(hipMalloc((void **)&dthr, nout), "hipMalloc"))) fail(TMAT_E_HIP);
+    if (!rc && !hip_ok(hipMemcpyAsync(din, imgs, nin * 2, hipMemcpyHostToDevice, s), "H2D")) fail(TMAT_E_HIP);
+    const uint16_t *small = din;
+    std::vector<int> r0, r1, c0, c1;
+    std::vector<float> wr0, wr1, wc0, wc1;
+    if (!rc && out_h) {
+        linear_axis(H, oh, r0, r1, wr0, wr1);
+        linear_axis(W, ow, c0, c1, wc0, wc1);
+        if (!hip_ok(hipMalloc((void **)&dsm, nout * 2), "hipMalloc") || !hip_ok(hipMalloc((void **)&itab, (size_t)(oh + ow) * 2 * 4), "hipMalloc") ||
+            !hip_ok(hipMalloc((void **)&ftab, (size_t)(oh + ow) * 2 * 4), "hipMalloc")) fail(TMAT_E_HIP);
+        if (!rc) {
+            int *dr0 = itab, *dr1 = dr0 + oh, *dc0 = dr1 + oh, *dc1 = dc0 + ow;
+            float *dwr0 = ftab, *dwr1 = dwr0 + oh, *dwc0 = dwr1 + oh, *dwc1 = dwc0 + ow;
+            bool ok = hipMemcpyAsync(dr0, r0.data(), oh * 4, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(dr1, r1.data(), oh * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
+                      hipMemcpyAsync(dc0, c0.data(), ow * 4, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(dc1, c1.data(), ow * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
+                      hipMemcpyAsync(dwr0, wr0.data(), oh * 4, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(dwr1, wr1.data(), oh * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
+                      hipMemcpyAsync(dwc0, wc0.data(), ow * 4, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(dwc1, wc1.data(), ow * 4, hipMemcpyHostToDevice, s) == hipSuccess;
+            if (!ok) { set_error("tmat_cell_area_batch: table upload failed"); fail(TMAT_E_HIP); }
+            else {
+                const int blocks = (oh * ow + 255) / 256;
+                hipLaunchKernelGGL(resize_linear_u16_kernel, dim3(blocks < 1024 ? blocks : 1024, n), dim3(256), 0, s, din, H, W, oh, ow, dr0, dr1, dwr0, dwr1, dc0, dc1,
+                                   dwc0, dwc1, dsm);
+                small = dsm;
+            }
+        }
+    }
+    if (!rc) {
+        const int npx = oh * ow, blocks = (npx + 255) / 256;
+        const dim3 grid(blocks < 512 ? blocks : 512, n);
+        if (!hip_ok(hipMemsetAsync(hist, 0, (size_t)n * 65536 * 4, s), "memset") || !hip_ok(hipMemsetAsync(kept, 0, n * 4, s), "memset")) fail(TMAT_E_HIP);
+        else {
+            hipLaunchKernelGGL(hist_u16_kernel, grid, dim3(256), 0, s, small, npx, hist);
+            hipLaunchKernelGGL(gmm_hist_kernel, dim3(n), dim3(1024), 0, s, hist, sd_coef, dpar);
+            hipLaunchKernelGGL(apply_threshold_kernel, grid, dim3(256), 0, s, small, npx, dpar, dthr, kept);
+            std::vector<unsigned> kh(n);
+            std::vector<double> ph((size_t)n * 11);
+            if (!hip_ok(hipGetLastError(), "launch") || !hip_ok(hipMemcpyAsync(kh.data(), kept, n * 4, hipMemcpyDeviceToHost, s), "D2H") ||
+                !hip_ok(hipMemcpyAsync(ph.data(), dpar, (size_t)n * 11 * 8, hipMemcpyDeviceToHost, s), "D2H") ||
+                (thresholded && !hip_ok(hipMemcpyAsync(thresholded, dthr, nout, hipMemcpyDeviceToHost, s), "D2H")) ||
+                !hip_ok(hipStreamSynchronize(s), "sync")) fail(TMAT_E_HIP);
+            else {
+                for (int i = 0; i < n; i++) area[i] = (double)kh[i] / (double)npx;          // compute_area_prop: np.sum(img > 0) / img.size
+                if (params) for (int i = 0; i < n; i++) for (int k = 0; k < 9; k++) params[(size_t)i * 9 + k] = ph[(size_t)i * 11 + k];
+            }
+        }
+    }
+    hipFree(din); hipFree(dsm); hipFree(hist); hipFree(kept); hipFree(dpar); hipFree(dthr); hipFree(itab); hipFree(ftab);
+    return rc;
+}

@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Compute the cell-covered area of a directory of images -- MI355X drop-in for the reference's scripts/compute_cell_area.py:
+same positional arguments, flags and config keys, same outputs (`thresholded/<id>_thresholded.png`,
+`calculations/cell_area.csv` with columns image_id, area_pct; -2, -3 ... when a name is taken), same exit behaviour.
+
+    python compute_cell_area.py IN_ROOT OUT_ROOT [--channel N] [--time N] [--sd-coef F] [-c CONFIG]
+
+Z stacks (slice sequences or multi-page files) are max-projected first, as in the reference.  Differences
+(INTEGRATION.md): images are thresholded in batches on the GPU (tmat_cell_area_batch); the gaussian-mixture fit is
+deterministic, so `rs_seed` has no effect; -w/--detect-well (an unseeded random search in the reference) and --time other
+than 0 are refused; files are read and written with Pillow.
+"""
+import argparse
+import csv
+import json
+import os
+import sys
+from glob import glob
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parents[1]
+if str(PKG) not in sys.path:
+    sys.path.insert(0, str(PKG))
+
+import numpy as np  # noqa: E402
+
+DEFAULT_CONFIG_PATH = str(PKG / "config" / "default_cell_area_computation.json")
+THRESH_SUBDIR = "thresholded"
+CALC_SUBDIR = "calculations"
+FAIL = "\033[91m[FAILURE]\033[0m"
+OK = "\033[92m[SUCCESS]\033[0m"
+WARN = "\033[93m[WARNING]\033[0m"
+
+
+def parse_cell_area_args(argv=None):
+    """same surface as the reference's script_util.parse_cell_area_args (script_util.py:208-298)"""
+    p = argparse.ArgumentParser()
+    p.add_argument("in_root", type=str)
+    p.add_argument("out_root", type=str)
+    p.add_argument("--channel", type=int, default=None)
+    p.add_argument("--time", type=int, default=None)
+    p.add_argument("-w", "--detect-well", action="store_true")
+    p.add_argument("--sd-coef", type=float, default=None)
+    p.add_argument("-c", "--config", type=str, default=DEFAULT_CONFIG_PATH)
+    args = p.parse_args(argv)
+    for k, v in vars(args).items():
+        if isinstance(v, str):
+            setattr(args, k, v.strip("'\""))
+    return args
+
+
+def get_unique_output_filepath(file):
+    file = Path(file)
+    name, ext = os.path.splitext(file.name)
+    n = 1
+    while file.exists():
+        n += 1
+        file = file.parent / f"{name}-{n}{ext}"
+    return file
+
+
+def main(argv=None):
+    args = parse_cell_area_args(argv)
+    from compute_branches import find_inputs, load_image_2d, load_stack            # the same discovery rule (script_util.py:506-553)
+    in_root = Path(args.in_root)
+    if not in_root.is_dir():
+        print(f"{FAIL} Input directory {in_root} does not exist.", flush=True)
+        sys.exit(1)
+    if not glob(str(in_root / "*")):
+        print(f"{FAIL}No images found in {in_root}", flush=True)
+        sys.exit(1)
+    if args.detect_well:
+        print(f"{FAIL} --detect-well is not available in the accelerated path (unseeded random search in the reference).", flush=True)
+        sys.exit(1)
+    paths, is_stack = find_inputs(in_root)
+    if not paths:
+        print(f"{FAIL}No images found in {in_root}", flush=True)
+        sys.exit(1)
+    out_root = Path(args.out_root)
+    if out_root.is_file():
+        print(f"{FAIL} Output path is a file: {out_root}", flush=True)
+        sys.exit(1)
+    try:
+        (out_root / THRESH_SUBDIR).mkdir(parents=True, exist_ok=True)
+        (out_root / CALC_SUBDIR).mkdir(parents=True, exist_ok=True)
+    except PermissionError as error:
+        print(f"{FAIL} {error}", flush=True)
+        sys.exit(1)
+    if not os.path.isfile(args.config):
+        print(f"{FAIL} Config file not found: {args.config}", flush=True)
+        sys.exit(1)
+    with open(args.config, "r", encoding="utf8") as fp:
+        config = json.load(fp)
+    dsamp_size = config["dsamp_size"]
+    sd_coef = config["sd_coef"] if args.sd_coef is None else args.sd_coef
+    batch_size = int(config["batch_size"])
+
+    from PIL import Image
+    from tmat_amd import _lib, preprocessing, zstacks
+    handle = _lib.Handle(None, 0)
+    if is_stack:
+        print(f"{WARN} Input images are Z stacks. Creating maximum intensity Z projections prior to cell area calculation.", flush=True)
+    img_ids = list(paths)                       # the reference keeps glob / dict order
+    areas, kept_all = {}, {}
+
+    def flush(group):
+        for shape, items in group.items():
+            area, kept = preprocessing.cell_area_batch(handle, np.stack([im for _, im in items]), dsamp_size, sd_coef)
+            for (img_id, _), a, k in zip(items, area, kept):
+                areas[img_id], kept_all[img_id] = a, k
+
+    for i0 in range(0, len(img_ids), batch_size):
+        group = {}
+        for img_id in img_ids[i0:i0 + batch_size]:
+            try:
+                if is_stack:
+                    img = zstacks.proj_max(load_stack(paths[img_id], args.channel, args.time), handle=handle)     # compute_cell_area.py:50-52
+                else:
+                    img = load_image_2d(paths[img_id], args.channel, args.time)
+            except (OSError, ValueError) as error:
+                print(f"{FAIL}{error}", flush=True)
+                sys.exit(1)
+            group.setdefault(img.shape, []).append((img_id, img))
+        flush(group)
+    print("... Areas computed successfully.", flush=True)
+    print(OK, flush=True)
+
+    out_ids = [i.replace("/", "_").replace("\\", "_") for i in img_ids]
+    for img_id, oid in zip(img_ids, out_ids):
+        file = get_unique_output_filepath(out_root / THRESH_SUBDIR / f"{oid}_thresholded.png")
+        Image.fromarray(kept_all[img_id]).save(file)
+    print(f"... Thresholded images saved to:{os.linesep}\t{out_root}/{THRESH_SUBDIR}", flush=True)
+    area_out_path = get_unique_output_filepath(out_root / CALC_SUBDIR / "cell_area.csv")
+    with open(area_out_path, "w", newline="") as f:           # pandas DataFrame.to_csv(index=False): header + repr of the floats
+        wr = csv.writer(f, lineterminator="\n")
+        wr.writerow(["image_id", "area_pct"])
+        for img_id, oid in zip(img_ids, out_ids):
+            wr.writerow([oid, repr(float(areas[img_id] * 100))])
+    print(f"... Area calculations saved to:{os.linesep}\t{area_out_path}", flush=True)
+    print(OK, flush=True)
+    handle.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,6 +72,7 @@ def lib():
     L.tmat_vessel_field.argtypes = [vp, vp, i, i, i, i, vp, vp]
     L.tmat_analyze_stack.argtypes = [vp, vp, i, i, i, i, i, f, f, i, i, i, i, C.c_int64, vp, vp]
     L.tmat_field_stats.argtypes = [vp, vp, i, i, f, f, i, i, i, i, C.c_int64, vp]
+    L.tmat_cell_area_batch.argtypes = [vp, vp, i, i, i, i, i, d, vp, vp, vp]
     L.tmat_prof_enable.argtypes = [vp, i]
     L.tmat_prof_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), i]
     for name in EXPORTS:
@@ -91,7 +92,7 @@ EXPORTS = [
     "tmat_host_rescale255_f32", "tmat_host_filter_mask", "tmat_host_skeletonize", "tmat_host_medial_axis",
     "tmat_host_permutation", "tmat_host_postprocess",
     "tmat_set_gaussian_table", "tmat_host_gaussian_kernel1d", "tmat_gaussian_f32", "tmat_sato_batch", "tmat_stack_prepare", "tmat_vessel_field",
-    "tmat_analyze_stack", "tmat_field_stats",
+    "tmat_analyze_stack", "tmat_field_stats", "tmat_cell_area_batch",
 ]
 
 

@@ -1,0 +1,43 @@
+"""Mirror of the cell-area part of fl_tissue_model_tools.preprocessing / scripts/compute_cell_area.py (reference
+preprocessing.py:44-93, compute_cell_area.py:29-87, 164-178) on the HIP library (csrc/cellarea_kernels.hip, no CPU fallback).
+
+The reference thresholds one float image at a time with scikit-learn's GaussianMixture; here a batch of uint16 images goes
+through tmat_cell_area_batch: bilinear down-sampling, rescale to 0..1, the mixture fitted to the intensity histogram,
+threshold, area.  The fit is deterministic (optimal 2-means start instead of sklearn's RandomState-seeded KMeans; float64
+EM), so it does not need the reference's `rand_state`; tests/test_oracle_cellarea.py states the tolerance against
+scikit-learn (0.1 percentage points of the image area).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from ._lib import Handle, check, lib, ptr
+
+
+def resized_shape(shape, dsamp_size):
+    """compute_cell_area.py:54-57: dsize = round(shape * dsamp_size / max(shape)) is handed to cv2 as (width, height)"""
+    ratio = dsamp_size / max(shape)
+    dsize = tuple(int(v) for v in np.round(np.multiply(shape, ratio)).astype(int))
+    return dsize[1], dsize[0]
+
+
+def cell_area_batch(handle: Handle, imgs: np.ndarray, dsamp_size=512, sd_coef: float = 0.0, return_params=False):
+    """imgs (n, H, W) uint8 / uint16 -> (area fractions (n,), thresholded images (n, h, w) uint8 0 / 255[, fit parameters (n, 9)])"""
+    a = np.asarray(imgs)
+    if a.ndim != 3 or a.dtype not in (np.uint8, np.uint16):
+        raise ValueError("cell_area_batch: expected (n, H, W) uint8 or uint16 images")
+    a = np.ascontiguousarray(a, np.uint16)
+    n, H, W = a.shape
+    oh, ow = resized_shape((H, W), dsamp_size) if dsamp_size is not None else (0, 0)
+    area = np.empty(n, np.float64)
+    out = np.empty((n, oh or H, ow or W), np.uint8)
+    params = np.empty((n, 9), np.float64)
+    check(lib().tmat_cell_area_batch(handle.raw, ptr(a), n, H, W, oh, ow, float(sd_coef), ptr(area), ptr(out), ptr(params)), "tmat_cell_area_batch")
+    return (area, out, params) if return_params else (area, out)
+
+
+def exec_threshold(handle: Handle, img: np.ndarray, sd_coef: float = 0.0) -> np.ndarray:
+    """preprocessing.exec_threshold for one integer image without a well mask: the image with background pixels set to 0"""
+    area, kept = cell_area_batch(handle, np.asarray(img)[None], None, sd_coef)
+    return np.where(kept[0] > 0, img, 0)

@@ -28,7 +28,7 @@ def _shims():
         "    if a and callable(a[0]):\n        return a[0]\n"
         "    return lambda f: f\n")
     (d / "cv2.py").write_text(
-        "COLOR_HSV2BGR = 54\nINTER_LANCZOS4 = 4\n"
+        "COLOR_HSV2BGR = 54\nINTER_LANCZOS4 = 4\nDIST_L2 = 2\nINTER_AREA = 3\n"
         "def cvtColor(a, code):\n    return a\n")
     sys.path.insert(0, str(d))
     sys.path.insert(0, str(REF))
@@ -341,6 +341,47 @@ def gen_sato():
     out["m_dil"] = np.packbits(dilation(m, square(3)))
     np.savez_compressed(GOLD / "sato.npz", **out)
     print("sato.npz", {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
+def cellarea_inputs():
+    """deterministic small uint16 images: vessels over a noisy background, regenerated by the tests from the seeds"""
+    sys.path.insert(0, str(REPO / "tissue-model-analysis-tools_amd"))
+    from tmat_amd import synth
+    return {f"c{i}": synth.synth_image(50 + i, 256, n_vessels=10 + 4 * i, scale=0.6)[:192, :224] for i in range(3)}
+
+
+def gen_cellarea():
+    """the reference's own preprocessing.exec_threshold (scikit-learn GaussianMixture inside) on rescaled images, as
+    compute_cell_area.mask_and_threshold calls it: RandomState(0), sd_coef 0 and 0.5, no well mask"""
+    import types
+    if "dask" not in sys.modules:
+        try:
+            import dask  # noqa: F401
+        except ImportError:
+            sys.modules["dask"] = types.ModuleType("dask")
+    # defs.py reads the install-time package.cfg (base_dir), which an uninstalled checkout does not have; the one constant
+    # exec_threshold takes from it is MAX_UINT8 = np.iinfo(np.uint8).max
+    import importlib
+    import importlib.util
+    pkg = importlib.import_module("fl_tissue_model_tools")
+    dm = types.ModuleType("fl_tissue_model_tools.defs")
+    dm.MAX_UINT8, dm.MAX_UINT16, dm.EPSILON = np.iinfo(np.uint8).max, np.iinfo(np.uint16).max, np.finfo(np.float32).eps
+    sys.modules["fl_tissue_model_tools.defs"] = dm
+    pkg.defs = dm
+    from fl_tissue_model_tools import preprocessing as prep
+    import sklearn
+    out = {"sklearn_version": np.array(sklearn.__version__)}
+    for k, img in cellarea_inputs().items():
+        lo, hi = float(img.min()), float(img.max())
+        x = ((img.astype(np.float64) - lo) / (hi - lo)).astype(np.float32)      # rescale_intensity(img, (0, 1)).astype(float32)
+        for sd in (0.0, 0.5):
+            rs = np.random.RandomState(0)
+            res = prep.exec_threshold(x, None, sd, rs)
+            kept = res > 0
+            out[f"{k}_sd{sd}_bits"] = np.packbits(kept)
+            out[f"{k}_sd{sd}_area"] = np.array(kept.sum() / kept.size)
+    np.savez_compressed(GOLD / "cellarea.npz", **out)
+    print("cellarea.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items()})
 
 
 if __name__ == "__main__":
