@@ -267,6 +267,26 @@ int tmat_field_stats(tmat_handle h, const float *field, int fh, int fw, float gr
 int tmat_cell_area_batch(tmat_handle h, const uint16_t *imgs, int n, int H, int W, int out_h, int out_w, double sd_coef,
                          double *area, uint8_t *thresholded, double *params);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Invasion-depth tool: reference scripts/compute_inv_depth.py:96-172, models.py:33-82 (build_ResNet50_TL),
+ * data_prep.py:17-61 (csrc/resnet_kernels.hip; the 1x1 / 3x3 convolutions run on the conv_mfma_kernel of the branching
+ * path).  A handle from tmat_create_plain is enough.
+ * --------------------------------------------------------------------------------------------------------------- */
+
+/* One classifier = keras.applications ResNet50 up to a `conv{N}_block{K}_out` layer + GlobalAveragePooling2D + Dense(1) +
+ * sigmoid.  weights_blob: "TMATW001" container (tmat_amd/inv_depth.py:pack_resnet) with Keras layouts -- conv1.{w,b,bn},
+ * s{stage}b{block}.c{1,2,3}.{w,b,bn} (+ .c0 for the projection shortcut of block 1), fc.{w,b}; bn = (4, C) gamma, beta,
+ * moving mean, moving variance, eps 1.001e-5.  Returns the model's id on this handle. */
+int tmat_resnet_load(tmat_handle h, const void *weights_blob, size_t n_bytes, int *model_id);
+/* model.predict(x): x (n, size, size, 3) float32 host (already preprocessed), prob (n) float32.  size % 32 == 0 */
+int tmat_resnet_predict(tmat_handle h, int model_id, const float *x, int n, int size, float *prob);
+/* compute_inv_depth.py:150-156 for one Z stack: data_prep.prep_inv_depth_imgs (cv2.resize to size x size -- bilinear: the
+ * interpolation argument sits in the position of `dst` --, rescale_intensity 0..255, three identical channels,
+ * resnet50.preprocess_input) and every model's prediction per slice.  stack (Z, H, W) u16 host; probs (Z, n_models);
+ * x_out (nullable): the prepared input (Z, size, size, 3) f32. */
+int tmat_inv_depth_predict(tmat_handle h, const int *model_ids, int n_models, const uint16_t *stack, int Z, int H, int W,
+                           int size, float *probs, float *x_out);
+
 /* device memory helpers so a ctypes host can stage inputs in HBM without torch */
 int tmat_dev_alloc(tmat_handle h, size_t bytes, void **dev_ptr);
 int tmat_dev_free(tmat_handle h, void *dev_ptr);

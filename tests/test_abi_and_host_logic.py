@@ -88,3 +88,22 @@ def test_mirror_modules_validate_arguments():
             transforms.filter_branch_seg_mask(m)
     with pytest.raises(TypeError):
         stp.predict_img_with_smooth_windowing(np.zeros((10, 10), np.float32), 320, 2, lambda b, verbose=0: b)
+
+
+def test_inv_depth_ensemble_selection_matches_the_reference_rule():
+    """compute_inv_depth.py:86-93 on the reference's own best_model_history_*.csv (shipped as package data): the per-model
+    minimum fine-tuning validation loss and its argsort, as pandas computes them (tests/golden/inv_depth_selection.npz)"""
+    from pathlib import Path
+    import numpy as np
+    from tmat_amd import inv_depth
+    g = np.load(Path(__file__).parent / "golden" / "inv_depth_selection.npz")
+    d = Path(inv_depth.__file__).resolve().parents[1] / "model_training" / "best_ensemble"
+    assert inv_depth.best_model_indices(d, 5, 5) == [int(v) for v in g["sorted_best_model_idx"]]
+    assert inv_depth.best_model_indices(d, 5, 3) == [int(v) for v in g["sorted_best_model_idx"][:3]]
+    # rounding / thresholding of the ensemble mean (compute_inv_depth.py:156-166)
+    probs = np.array([[0.2, 0.4, 0.9], [0.49994, 0.5, 0.50016], [0.5002, 0.5002, 0.5002], [0.1, 0.1, 0.1]], np.float32)
+    got = inv_depth.ensemble_predictions(probs, 0.5)
+    # the mean is rounded to 4 places BEFORE it is compared with the threshold: 0.50003 -> 0.5 -> "no invasion"
+    assert [lab for _, lab in got] == [0, 0, 1, 0] and str(got[1][0]) == "0.5" and str(got[2][0]) == "0.5002"
+    names = [n for n, _ in inv_depth.layer_plan()]
+    assert names[0] == "conv1.w" and "s4b6.c3.bn" in names and "s5b1.c1.w" not in names and "s3b1.c0.w" in names and "s3b2.c0.w" not in names

@@ -38,3 +38,21 @@ def test_h5_roundtrip(tmp_path, nested):
     for k in w:
         assert got[k].shape == w[k].shape and np.array_equal(got[k], w[k]), k
     assert dst.read_bytes() == src.read_bytes()         # the container itself is reproduced byte for byte
+
+
+@pytest.mark.skipif(not _has_h5py(), reason="no interpreter with h5py")
+def test_resnet_h5_roundtrip(tmp_path):
+    """the invasion-depth classifier's weight file (build_ResNet50_TL + save_weights layout) -> TMATW001, tensor by tensor"""
+    from tmat_amd import inv_depth, synth
+    w = inv_depth.synth_resnet_weights(4, "conv3_block2_out")
+    src = tmp_path / "in.tmatw"
+    src.write_bytes(inv_depth.pack_resnet(w))
+    h5, dst = tmp_path / "best_finetune_weights_0.h5", tmp_path / "out.tmatw"
+    r = subprocess.run([str(PY), str(REPO / "tests" / "helpers" / "write_keras_resnet_h5.py"), str(src), str(h5)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(PY), str(REPO / "tools" / "convert_keras_h5.py"), "--resnet", str(h5), str(dst)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = synth.unpack_weights(dst.read_bytes())
+    assert list(got) == list(w)
+    for k in w:
+        assert got[k].shape == w[k].shape and np.array_equal(got[k], w[k]), k

@@ -30,9 +30,8 @@ bool hip_ok(hipError_t e, const char *what)
 // ---------------------------------------------------------------------------------------------
 // weight container ("TMATW001", tmat_amd/synth.py:pack_weights)
 // ---------------------------------------------------------------------------------------------
-struct Tensor { std::vector<int> shape; const float *data; size_t count; };
 
-static bool parse_blob(const void *blob, size_t nbytes, std::map<std::string, Tensor> &out, int &patch)
+bool parse_blob(const void *blob, size_t nbytes, std::map<std::string, Tensor> &out, int &patch)
 {
     const uint8_t *p = (const uint8_t *)blob;
     if (nbytes < 16 || memcmp(p, "TMATW001", 8)) { set_error("weights: bad magic"); return false; }
@@ -114,7 +113,7 @@ static std::vector<float> subpixel_weights(const std::vector<float> &w9, int I, 
 }
 
 // [taps][I][O] -> [taps][O][I]: the MFMA convolution reads both operands k-contiguous (unet_kernels.hip)
-static std::vector<float> k_contiguous(const float *w, int taps, int I, int O)
+std::vector<float> k_contiguous(const float *w, int taps, int I, int O)
 {
     std::vector<float> r((size_t)taps * I * O);
     for (int t = 0; t < taps; t++)
@@ -548,6 +547,7 @@ void tmat_destroy(tmat_handle h)
     if (c->win1d) hipFree(c->win1d);
     if (c->ma_table) hipFree(c->ma_table);
     for (auto &g : c->gauss_dev) hipFree(g.second);
+    for (auto &m : c->resnets) for (void *p : m.owned) hipFree(p);
     c->free_pass();
     for (auto &e : c->ev_open) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
     for (auto e : c->ev_pool) hipEventDestroy(e);

@@ -64,6 +64,23 @@ struct PassBuf {
     hipEvent_t done[2] = {nullptr, nullptr};
 };
 
+// weight container ("TMATW001", tmat_amd/synth.py:pack_weights): tensors by name, pointing into the caller's blob
+struct Tensor { std::vector<int> shape; const float *data; size_t count; };
+bool parse_blob(const void *blob, size_t nbytes, std::map<std::string, Tensor> &out, int &patch);
+std::vector<float> k_contiguous(const float *w, int taps, int I, int O);        // [taps][I][O] -> [taps][O][I]
+
+// ResNet50 classifier of the invasion-depth tool (resnet_kernels.hip)
+struct ResConv { int cin = 0, cout = 0, ksize = 1, stride = 1; float *w = nullptr, *scale = nullptr, *shift = nullptr; };
+struct ResBlock { ResConv c1, c2, c3, sc; bool has_sc = false; };
+struct ResNetModel {
+    float *stem_w = nullptr, *stem_scale = nullptr, *stem_shift = nullptr;      // [147][64], folded BN
+    std::vector<ResBlock> blocks;
+    float *fc_w = nullptr;
+    float fc_b = 0.f;
+    int feat = 0;                                                               // channels of the last block
+    std::vector<void *> owned;
+};
+
 struct GaussKey {
     double sigma; int order, radius;
     bool operator<(const GaussKey &o) const { return sigma != o.sigma ? sigma < o.sigma : order != o.order ? order < o.order : radius < o.radius; }
@@ -71,6 +88,7 @@ struct GaussKey {
 
 struct Ctx {
     int device = 0;
+    std::vector<ResNetModel> resnets;                        // invasion-depth classifiers loaded on this handle (tmat_resnet_load)
     std::map<GaussKey, GaussTable> gauss;                    // gaussian kernel tables (gauss_tables.cpp)
     std::map<const GaussTable *, double *> gauss_dev;        // their device copies (stack_pipeline.cpp)
     hipStream_t stream = nullptr;

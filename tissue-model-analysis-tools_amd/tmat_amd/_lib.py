@@ -73,6 +73,9 @@ def lib():
     L.tmat_analyze_stack.argtypes = [vp, vp, i, i, i, i, i, f, f, i, i, i, i, C.c_int64, vp, vp]
     L.tmat_field_stats.argtypes = [vp, vp, i, i, f, f, i, i, i, i, C.c_int64, vp]
     L.tmat_cell_area_batch.argtypes = [vp, vp, i, i, i, i, i, d, vp, vp, vp]
+    L.tmat_resnet_load.argtypes = [vp, vp, sz, C.POINTER(i)]
+    L.tmat_resnet_predict.argtypes = [vp, i, vp, i, i, vp]
+    L.tmat_inv_depth_predict.argtypes = [vp, vp, i, vp, i, i, i, i, vp, vp]
     L.tmat_prof_enable.argtypes = [vp, i]
     L.tmat_prof_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), i]
     for name in EXPORTS:
@@ -93,6 +96,7 @@ EXPORTS = [
     "tmat_host_permutation", "tmat_host_postprocess",
     "tmat_set_gaussian_table", "tmat_host_gaussian_kernel1d", "tmat_gaussian_f32", "tmat_sato_batch", "tmat_stack_prepare", "tmat_vessel_field",
     "tmat_analyze_stack", "tmat_field_stats", "tmat_cell_area_batch",
+    "tmat_resnet_load", "tmat_resnet_predict", "tmat_inv_depth_predict",
 ]
 
 
