@@ -103,3 +103,28 @@ def test_run_sharded_world2_equals_world1(tmp_path):
     for f in files:
         a, b = (o1 / f).read_text(), (o2 / f).read_text()
         assert a == b and a.count("\n") == 11
+
+
+RAGGED = r"""
+import sys
+sys.path.insert(0, r"{repo}"); sys.path.insert(0, r"{repo}/tissue-model-analysis-tools_amd")
+from tmat_amd import distributed
+ws, rank, _ = distributed.init_process_group_from_env()
+depth = [3, 0, 7, 1, 2]                                   # slices per stack: ragged rows per rank
+rows = []
+for si in distributed.shard_indices(len(depth), rank, ws):
+    rows += [(int(si) * (1 << 20) + z, z % 2, 0.125 * z + int(si), 0.0) for z in range(depth[int(si)])]
+allrows = distributed.gather_rows_ragged(rows)
+expect = [(si * (1 << 20) + z, z % 2, 0.125 * z + si, 0.0) for si in range(len(depth)) for z in range(depth[si])]
+assert allrows == expect, (rank, allrows, expect)
+distributed.finish_process_group()
+print("rank", rank, "ok", len(allrows))
+"""
+
+
+def test_gather_rows_ragged_world2(tmp_path):
+    """the invasion-depth script's exchange: one row per Z slice, stacks of different depth on different ranks"""
+    script = tmp_path / "ragged.py"
+    script.write_text(RAGGED.format(repo=str(REPO)))
+    assert _run(script, [], 2).count("ok") == 2
+    assert _run(script, [], 1).count("ok") == 1

@@ -96,11 +96,15 @@ def main(argv=None):
     batch_size = int(config["batch_size"])
 
     from PIL import Image
-    from tmat_amd import _lib, preprocessing, zstacks
-    handle = _lib.Handle(None, 0)
+    from tmat_amd import _lib, distributed, preprocessing, zstacks
+    # one process per GPU under torch.distributed.run: images are independent, every rank takes a contiguous block of them,
+    # rank 0 writes the CSV from the gathered rows; every rank writes the thresholded pictures of its own images
+    ws, rank, local_rank = distributed.init_process_group_from_env()
+    handle = _lib.Handle(None, local_rank)
     if is_stack:
         print(f"{WARN} Input images are Z stacks. Creating maximum intensity Z projections prior to cell area calculation.", flush=True)
-    img_ids = list(paths)                       # the reference keeps glob / dict order
+    img_ids = sorted(paths)                     # a deterministic order: the ranks must agree on it (the reference keeps glob order)
+    mine = [img_ids[int(i)] for i in distributed.shard_indices(len(img_ids), rank, ws)]
     areas, kept_all = {}, {}
 
     def flush(group):
@@ -109,9 +113,9 @@ def main(argv=None):
             for (img_id, _), a, k in zip(items, area, kept):
                 areas[img_id], kept_all[img_id] = a, k
 
-    for i0 in range(0, len(img_ids), batch_size):
+    for i0 in range(0, len(mine), batch_size):
         group = {}
-        for img_id in img_ids[i0:i0 + batch_size]:
+        for img_id in mine[i0:i0 + batch_size]:
             try:
                 if is_stack:
                     img = zstacks.proj_max(load_stack(paths[img_id], args.channel, args.time), handle=handle)     # compute_cell_area.py:50-52
@@ -126,9 +130,17 @@ def main(argv=None):
     print(OK, flush=True)
 
     out_ids = [i.replace("/", "_").replace("\\", "_") for i in img_ids]
-    for img_id, oid in zip(img_ids, out_ids):
+    for img_id in mine:
+        oid = out_ids[img_ids.index(img_id)]
         file = get_unique_output_filepath(out_root / THRESH_SUBDIR / f"{oid}_thresholded.png")
         Image.fromarray(kept_all[img_id]).save(file)
+    index_of = {img_id: i for i, img_id in enumerate(img_ids)}
+    gathered = distributed.gather_rows([(index_of[i], 0, areas[i], 0.0) for i in mine], n_total=len(img_ids))
+    areas = {img_ids[g[0]]: g[2] for g in gathered}
+    if rank != 0:
+        handle.close()
+        distributed.finish_process_group()
+        return
     print(f"... Thresholded images saved to:{os.linesep}\t{out_root}/{THRESH_SUBDIR}", flush=True)
     area_out_path = get_unique_output_filepath(out_root / CALC_SUBDIR / "cell_area.csv")
     with open(area_out_path, "w", newline="") as f:           # pandas DataFrame.to_csv(index=False): header + repr of the floats
@@ -139,6 +151,7 @@ def main(argv=None):
     print(f"... Area calculations saved to:{os.linesep}\t{area_out_path}", flush=True)
     print(OK, flush=True)
     handle.close()
+    distributed.finish_process_group()
 
 
 if __name__ == "__main__":

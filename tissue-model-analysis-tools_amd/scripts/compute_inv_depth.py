@@ -110,10 +110,12 @@ def main(argv=None):
         print(f"{FAIL} resnet_inp_shape {resnet_inp_shape}: only square 3-channel inputs are supported.", flush=True)
         sys.exit(1)
 
-    from tmat_amd import _lib, helper, inv_depth, zstacks as zs
+    from tmat_amd import _lib, distributed, helper, inv_depth, zstacks as zs
     best_ensemble_dir = MODEL_TRAINING_DIR / "best_ensemble"
     order = inv_depth.best_model_indices(best_ensemble_dir, n_models, n_pred_models)
-    handle = _lib.Handle(None, 0)
+    # one process per GPU under torch.distributed.run: every rank holds the ensemble and takes a contiguous block of the stacks
+    ws, rank, local_rank = distributed.init_process_group_from_env()
+    handle = _lib.Handle(None, local_rank)
     blobs = []
     for i, idx in enumerate(order):
         print(f"Loading classifier {i}...", flush=True)
@@ -139,7 +141,10 @@ def main(argv=None):
         sys.exit(1)
 
     rows = []
-    for zstack_id, zstack_path in zstack_paths.items():
+    stack_ids = sorted(zstack_paths)              # a deterministic order the ranks agree on
+    for si in distributed.shard_indices(len(stack_ids), rank, ws):
+        zstack_id = stack_ids[int(si)]
+        zstack_path = zstack_paths[zstack_id]
         print(f"Processing {zstack_id}...", flush=True)
         try:
             if isinstance(zstack_path, str) and zstack_path.endswith(".npy"):
@@ -153,8 +158,13 @@ def main(argv=None):
             img = img[None]
         probs = ens.predict_stack(img)                              # (Z, n_pred_models): yhatp_m of compute_inv_depth.py:154
         for z, (inv_prob, inv_label) in enumerate(inv_depth.ensemble_predictions(probs, cls_thresh)):
-            rows.append((f"{zstack_id}_z{z}", inv_prob, inv_label))
+            rows.append((int(si) * (1 << 20) + z, inv_label, float(inv_prob), 0.0))       # float32 -> float64 is exact; back below
 
+    rows = [(f"{stack_ids[r[0] >> 20]}_z{r[0] & ((1 << 20) - 1)}", np.float32(r[2]), r[1]) for r in distributed.gather_rows_ragged(rows)]
+    if rank != 0:
+        handle.close()
+        distributed.finish_process_group()
+        return
     print("Saving results...", flush=True)
     out_csv_path = get_unique_output_filepath(out_root / "invasion_depth_predictions.csv")
     with open(out_csv_path, "w", newline="") as f:               # pandas DataFrame.to_csv with the slice ids as the index
@@ -165,6 +175,7 @@ def main(argv=None):
     print("... Results saved.", flush=True)
     print(OK, flush=True)
     handle.close()
+    distributed.finish_process_group()
 
 
 if __name__ == "__main__":

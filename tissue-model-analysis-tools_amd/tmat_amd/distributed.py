@@ -59,3 +59,38 @@ def gather_rows(rows_local, n_total=None, device=None):
     allrows = out.cpu().numpy().view(ROW_DTYPE)
     allrows = allrows[allrows["index"] >= 0]
     return sorted(((int(r["index"]), int(r["count"]), float(r["total"]), float(r["avg"])) for r in allrows), key=lambda r: r[0])
+
+
+def init_process_group_from_env():
+    """(world_size, rank, local_rank); under torch.distributed.run the process group is created (nccl = RCCL when a GPU is
+    visible, gloo otherwise) and this rank's device selected"""
+    ws, rank, local_rank = world()
+    if ws > 1:
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if backend == "nccl":
+                torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend)
+    return ws, rank, local_rank
+
+
+def finish_process_group():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def gather_rows_ragged(rows_local, device=None):
+    """gather_rows for shards whose row counts are not known up front (the invasion-depth tool: one row per Z slice, stacks of
+    different depth): an all-reduce(max) of the local counts fixes the shard capacity, then the one all-gather"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return sorted(rows_local, key=lambda r: r[0])
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    cap = torch.tensor([len(rows_local)], dtype=torch.int64, device=dev)
+    dist.all_reduce(cap, op=dist.ReduceOp.MAX)
+    return gather_rows(rows_local, n_total=int(cap.item()) * dist.get_world_size(), device=device)
