@@ -328,6 +328,11 @@ __global__ __launch_bounds__(512, SEP_WPS) void sepconv_mfma_kernel(SepArgs a, i
         }
     };
 
+#ifdef SEP_ABL_VMCNT      // timing ablation only (racy): leave the newest DMA group in flight across the step barrier
+#define SEP_STEP_WAIT() asm volatile("s_waitcnt vmcnt(%0)" :: "n"(SEP_ABL_VMCNT) : "memory");
+#else
+#define SEP_STEP_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 #define SEP_STEP(SA, SB, SC)                                                                                    \
     {                                                                                                           \
         const char *sa = reinterpret_cast<const char *>(SA);                                                    \
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(512, SEP_WPS) void sepconv_mfma_kernel(SepArgs a, i
         /* seg 5 */ SEP_RD(sb, tvB, twB, 0, 6) SEP_RB(sa, bqa, 1, 2) SEP_MM(a1.y, bqb) SEP_FM(a0, tvA, twA) SEP_MIX(NV) SEP_PIN() \
         /* seg 6 */ SEP_RD(sb, tvA, twA, 1, 0) SEP_RB(sa, bqb, 1, 3) SEP_MM(a1.z, bqa) SEP_FM(a0, tvB, twB) SEP_MIX(NV) SEP_PIN() \
         /* seg 7 */ SEP_RB(sb, bqa, 0, 0) SEP_MM(a1.w, bqb) SEP_PIN()                                           \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
+        SEP_STEP_WAIT()                                                                                         \
         __syncthreads();                                                                                        \
         if (++cc == nchunks) { cc = 0; if (POOL) store_tile_pool(cj); else store_tile(cj); cj++; }                                                  \
         if (--left == 0) break;                                                                                 \
