@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void ma_dep_kernel(const uint64_t *__restrict_
 constexpr int MA_T = 64, MA_R = 16, MA_S = MA_T + 2 * MA_R;      // tile, halo = rounds per launch, staged side
 __global__ __launch_bounds__(256) void ma_round_kernel(const uint8_t *__restrict__ sd, uint8_t *__restrict__ sd_out, const uint8_t *__restrict__ dep,
                                                        int H, int W, const uint32_t *__restrict__ table, int *__restrict__ undone,
-                                                       const int *__restrict__ active)
+                                                       const int *__restrict__ active, uint8_t *__restrict__ tile_final)
 {
     __shared__ uint8_t s_a[MA_S * MA_S];
     __shared__ uint8_t s_b[MA_S * MA_S];
@@ -153,6 +153,10 @@ __global__ __launch_bounds__(256) void ma_round_kernel(const uint8_t *__restrict
     __shared__ int any;
     const int img = blockIdx.z;
     const size_t per = (size_t)H * W;
+    // A tile whose pixels were all done in the INPUT snapshot of some launch has been copied to the other snapshot by that
+    // launch: both copies are final and every later launch skips it (its neighbours read final values from either copy).
+    uint8_t *final_flag = tile_final + ((size_t)img * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (*final_flag) return;
     const uint8_t *g_sd = sd + img * per;
     uint8_t *g_out = sd_out + img * per;
     const uint8_t *g_dp = dep + img * per;
@@ -175,8 +179,14 @@ __global__ __launch_bounds__(256) void ma_round_kernel(const uint8_t *__restrict
     const int noff[8] = {-MA_S - 1, -MA_S, -MA_S + 1, -1, 1, MA_S - 1, MA_S, MA_S + 1};
     uint8_t *cur = s_a, *nxt = s_b;
     // a staged area without an undone pixel (most tiles after the first launches) only copies through
-    bool undone_here = false;
-    for (int i = t; i < MA_S * MA_S; i += 256) undone_here |= !(s_a[i] & 2);
+    bool undone_here = false, undone_inner = false;
+    for (int i = t; i < MA_S * MA_S; i += 256) {
+        const bool u = !(s_a[i] & 2);
+        const int ly = i / MA_S, lx = i - ly * MA_S;
+        undone_here |= u;
+        undone_inner |= u && ly >= MA_R && ly < MA_R + MA_T && lx >= MA_R && lx < MA_R + MA_T;
+    }
+    const bool inner_done_at_input = !__syncthreads_or(undone_inner);
     const bool work = __syncthreads_or(undone_here) && !idle;
     for (int r = 0; r < (work ? MA_R : 0); r++) {
         bool changed = false;
@@ -216,6 +226,7 @@ __global__ __launch_bounds__(256) void ma_round_kernel(const uint8_t *__restrict
     if (left) any = 1;
     __syncthreads();
     if (t == 0 && any) atomicOr(&undone[img], 1);
+    if (t == 0 && inner_done_at_input) *final_flag = 1;
 }
 
 __global__ __launch_bounds__(256) void ma_finish_kernel(const uint8_t *__restrict__ sd, size_t total, uint8_t *__restrict__ skel)
@@ -228,7 +239,8 @@ bool thin_dev_supported(int H, int W) { return H >= 1 && W >= 1 && (unsigned lon
 size_t thin_workspace_bytes(int n, int H, int W)
 {
     const size_t per = (size_t)H * W;
-    return (size_t)n * per * (8 + 1 + 1 + 1) + (size_t)n * 2 * sizeof(int) * 64 + (size_t)n * ((per + 1023) / 1024) * sizeof(int) + 512;
+    const size_t tiles = (size_t)((H + MA_T - 1) / MA_T) * ((W + MA_T - 1) / MA_T);
+    return (size_t)n * per * (8 + 1 + 1 + 1) + (size_t)n * 2 * sizeof(int) * 64 + (size_t)n * ((per + 1023) / 1024) * sizeof(int) + n * tiles + 1024;
 }
 
 int thin_count_dev(const uint8_t *mask, int n, int H, int W, int *nfg, hipStream_t s)
@@ -253,6 +265,9 @@ int thin_dev(const uint8_t *mask, const double *dist, const uint32_t *tie, const
     int *flags = (int *)(((uintptr_t)(dep + (size_t)n * per) + 15) & ~(uintptr_t)15);       // [launch][image] undone flags
     int *chunk = flags + (size_t)n * 2 * 64;                                                // per-chunk foreground counts -> offsets
     const int nchunk = (int)((per + 1023) / 1024);
+    const size_t tiles = (size_t)((H + MA_T - 1) / MA_T) * ((W + MA_T - 1) / MA_T);
+    uint8_t *tile_final = (uint8_t *)(chunk + (size_t)n * nchunk);                          // [image][tile]: both snapshots hold the tile's final values
+    if (hipMemsetAsync(tile_final, 0, (size_t)n * tiles, s) != hipSuccess) return -2;
     hipLaunchKernelGGL(ma_chunk_count_kernel, dim3(nchunk, n), dim3(1024), 0, s, mask, per, nchunk, chunk);
     hipLaunchKernelGGL(ma_chunk_scan_kernel, dim3(n), dim3(1024), 0, s, chunk, nchunk);
     hipLaunchKernelGGL(ma_keys_kernel, dim3(nchunk, n), dim3(1024), 0, s, mask, dist, H, W, tie, chunk, nchunk, keys);
@@ -266,7 +281,7 @@ int thin_dev(const uint8_t *mask, const double *dist, const uint32_t *tie, const
         if (hipMemsetAsync(flags, 0, (size_t)GROUP * n * sizeof(int), s) != hipSuccess) return -2;
         for (int g = 0; g < GROUP; g++) {                   // GROUP is even: the current copy is `sd` again after a group
             hipLaunchKernelGGL(ma_round_kernel, grid, dim3(256), 0, s, (g & 1) ? sd2 : sd, (g & 1) ? sd : sd2, dep, H, W, table_dev,
-                               flags + (size_t)g * n, g ? flags + (size_t)(g - 1) * n : (const int *)nullptr);
+                               flags + (size_t)g * n, g ? flags + (size_t)(g - 1) * n : (const int *)nullptr, tile_final);
         }
         if (hipMemcpyAsync(host.data(), flags + (size_t)(GROUP - 1) * n, n * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess) return -2;
