@@ -140,3 +140,25 @@ def test_bad_arguments(plain):
         sato.vessel_field(plain, np.zeros((1, 16, 16), np.float32))          # a single slice has no slice pair
     w = np.ones(3)
     assert _lib.lib().tmat_set_gaussian_table(plain.raw, -1.0, 0, 1, _lib.ptr(w)) != 0
+
+
+def test_two_slice_stack_and_odd_geometry(plain):
+    """Z = 2 (one slice pair: the volume's Z axis has length 1 in the unsharp mask's 3-D gaussian) on a field whose sides are not
+    multiples of the kernels' tile sizes"""
+    from oracle import sato as osato
+    from tmat_amd import sato, synth
+    stack = synth.synth_stack(21, 2, 2 * 75, 2 * 101, n_vessels=6)
+    vol = osato.stack_prepare(stack, (75, 101))
+    field, st = sato.vessel_field(plain, vol, "gaussian_derivatives", return_stages=True)
+    ofield, ost = osato.vessel_field(vol, return_stages=True, hessian="gaussian_derivatives")
+    assert same_bits(st["sharp"], ost["sharp"]) and np.array_equal(st["edges"], ost["edges"]) and np.array_equal(st["filt"], ost["filt"])
+    assert same_bits(field, ofield)
+
+
+def test_blank_stack_gives_an_empty_result(plain):
+    """no signal at all: no edges, an all-zero field, no branches (the reference prints "No branches found" and writes no row
+    for such an image; here the row carries a count of 0)"""
+    from tmat_amd import sato
+    stack = np.full((3, 128, 160), 1000, np.uint16)
+    n, tot, avg, field = sato.analyze_stack(plain, stack, 5, 10, 5, 5, None, False, return_field=True)
+    assert n == 0 and tot == 0 and not field.any()
