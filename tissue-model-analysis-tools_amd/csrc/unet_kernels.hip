@@ -603,56 +603,64 @@ __device__ __forceinline__ float exp_det(float x)
 // [C/4][4 classes][4 slots][4] are wave-uniform: hipcc reads them with scalar loads, so LDS only carries the pixels.
 // One block = 8 x 16 stored pixels (16 x 32 outputs); the 10 x 18 stored pixels they touch are staged in LDS with the
 // pixel stride padded to C + 4 floats (conflict-free 16-byte reads of neighbouring pixels).
-__global__ __launch_bounds__(128) void final_kernel(const float *__restrict__ S, int h, int w, int C,
+__global__ __launch_bounds__(128) void final_kernel(const float *__restrict__ S, int h, int w, int C, int CB,
                                                     const float *__restrict__ Wq, float bias, float *__restrict__ out)
 {
-    extern __shared__ __attribute__((aligned(16))) float tile[];    // [10][18][C + 4]
-    const int CP = C + 4;
+    // The channels go through LDS in blocks of CB (the chain order -- 4-channel groups ascending -- is unchanged, the four
+    // accumulators live in registers across the blocks): with CB = 32 a workgroup holds 25 KiB instead of 49, six of them
+    // fit a CU instead of three, and the fill of one overlaps the arithmetic of the others.
+    extern __shared__ __attribute__((aligned(16))) float tile[];    // [10][18][CB + 4]
+    const int CP = CB + 4;
     const int n = blockIdx.z;
     const int j0 = blockIdx.x * 16, i0 = blockIdx.y * 8;
-    const int C4 = C >> 2;
-    // tile fill in batches of 8 loads per thread (all in flight together), then 8 LDS stores
-    const int total = 10 * 18 * C4;
-    for (int e0 = threadIdx.x; e0 < total; e0 += 128 * 8) {
-        float4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int e = e0 + u * 128;
-            const int cq = e % C4, p = e / C4;
-            const int ly = i0 - 1 + p / 18, lx = j0 - 1 + p % 18;
-            const bool ok = e < total && ly >= 0 && ly < h && lx >= 0 && lx < w;
-            v[u] = *reinterpret_cast<const float4 *>(S + (ok ? (((size_t)n * h + ly) * w + lx) * C + cq * 4 : (size_t)0));
-            if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int e = e0 + u * 128;
-            if (e < total) *reinterpret_cast<float4 *>(tile + (e / C4) * CP + (e % C4) * 4) = v[u];
-        }
-    }
-    __syncthreads();
+    const int B4 = CB >> 2;
     const int qy = threadIdx.x >> 4, qx = threadIdx.x & 15;
     const int i = i0 + qy, jj = j0 + qx;
-    if (i >= h || jj >= w) return;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};             // classes (py, px) = (0,0), (0,1), (1,0), (1,1)
     const float *t0 = tile + (qy * 18 + qx) * CP;    // stored pixel (i - 1, j - 1)
-    for (int cg = 0; cg < C4; cg++) {
-        float4 v[3][3];
+    const int total = 10 * 18 * B4;
+    for (int cb = 0; cb < C; cb += CB) {
+        if (cb) __syncthreads();                     // the previous block of channels has been consumed
+        // tile fill in batches of 8 loads per thread (all in flight together), then 8 LDS stores
+        for (int e0 = threadIdx.x; e0 < total; e0 += 128 * 8) {
+            float4 v[8];
 #pragma unroll
-        for (int r = 0; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) v[r][c] = *reinterpret_cast<const float4 *>(t0 + (r * 18 + c) * CP + cg * 4);
-        const float *wq = Wq + cg * 64;
-#pragma unroll
-        for (int cls = 0; cls < 4; cls++)
-#pragma unroll
-            for (int tp = 0; tp < 4; tp++) {
-                const float4 x = v[(cls >> 1) + (tp >> 1)][(cls & 1) + (tp & 1)];
-                const float *ww = wq + (cls * 4 + tp) * 4;
-                acc[cls] = fmaf(x.x, ww[0], acc[cls]); acc[cls] = fmaf(x.y, ww[1], acc[cls]);
-                acc[cls] = fmaf(x.z, ww[2], acc[cls]); acc[cls] = fmaf(x.w, ww[3], acc[cls]);
+            for (int u = 0; u < 8; u++) {
+                const int e = e0 + u * 128;
+                const int cq = e % B4, p = e / B4;
+                const int ly = i0 - 1 + p / 18, lx = j0 - 1 + p % 18;
+                const bool ok = e < total && ly >= 0 && ly < h && lx >= 0 && lx < w;
+                v[u] = *reinterpret_cast<const float4 *>(S + (ok ? (((size_t)n * h + ly) * w + lx) * C + cb + cq * 4 : (size_t)0));
+                if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = e0 + u * 128;
+                if (e < total) *reinterpret_cast<float4 *>(tile + (e / B4) * CP + (e % B4) * 4) = v[u];
+            }
+        }
+        __syncthreads();
+        if (i < h && jj < w) {
+            for (int cg = 0; cg < B4; cg++) {
+                float4 v[3][3];
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) v[r][c] = *reinterpret_cast<const float4 *>(t0 + (r * 18 + c) * CP + cg * 4);
+                const float *wq = Wq + ((cb >> 2) + cg) * 64;
+#pragma unroll
+                for (int cls = 0; cls < 4; cls++)
+#pragma unroll
+                    for (int tp = 0; tp < 4; tp++) {
+                        const float4 x = v[(cls >> 1) + (tp >> 1)][(cls & 1) + (tp & 1)];
+                        const float *ww = wq + (cls * 4 + tp) * 4;
+                        acc[cls] = fmaf(x.x, ww[0], acc[cls]); acc[cls] = fmaf(x.y, ww[1], acc[cls]);
+                        acc[cls] = fmaf(x.z, ww[2], acc[cls]); acc[cls] = fmaf(x.w, ww[3], acc[cls]);
+                    }
+            }
+        }
     }
+    if (i >= h || jj >= w) return;
     const int W = 2 * w;
     float *o = out + ((size_t)n * 2 * h + 2 * i) * W + 2 * jj;
     float2 r0, r1;
@@ -666,8 +674,10 @@ __global__ __launch_bounds__(128) void final_kernel(const float *__restrict__ S,
 void launch_final(const float *S, int N, int h, int w, int C, const float *Wq, float bias, float *out, hipStream_t s)
 {
     dim3 grid((w + 15) / 16, (h + 7) / 8, N);
-    const size_t lds = (size_t)(10 * 18 * (C + 4)) * sizeof(float);
-    hipLaunchKernelGGL(final_kernel, grid, dim3(128), lds, s, S, h, w, C, Wq, bias, out);
+    static const int cb_env = [] { const char *e = getenv("TMAT_FINAL_CB"); return e ? atoi(e) : 32; }();
+    const int CB = (cb_env > 0 && cb_env % 4 == 0 && C % cb_env == 0) ? cb_env : C;      // channels per LDS block
+    const size_t lds = (size_t)(10 * 18 * (CB + 4)) * sizeof(float);
+    hipLaunchKernelGGL(final_kernel, grid, dim3(128), lds, s, S, h, w, C, CB, Wq, bias, out);
 }
 
 }  // namespace tmat
