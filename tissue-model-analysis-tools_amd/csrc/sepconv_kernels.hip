@@ -231,11 +231,18 @@ __global__ __launch_bounds__(64 * NW, SEP_WPS) void sepconv_mfma_kernel(SepArgs 
     float bqa[4], bqb[4];
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
 
+#ifdef SEP_ABL_NORD       // timing ablation: no halo / tap reads
+#define SEP_RD(st, tv, tw, g, t0) _Pragma("unroll") for (int u = 0; u < 3; u++) { tv[u] = make_float4(1.f, 2.f, 3.f, 4.f); tw[u] = make_float4(.1f, .2f, .3f, .4f); }
+#else
+#define SEP_RD_REAL 1
+#endif
+#ifdef SEP_RD_REAL
 #define SEP_RD(st, tv, tw, g, t0)                                                                               \
     _Pragma("unroll") for (int u = 0; u < 3; u++) {                                                             \
         tv[u] = *reinterpret_cast<const float4 *>(st + hoff[t0 + u] + g * (SEP_HPLANE * 16));                   \
         tw[u] = *reinterpret_cast<const float4 *>(st + doff + (t0 + u) * 64 + g * 32);                          \
     }
+#endif
 #ifdef SEP_ABL_NODW
 #define SEP_FM(av, tv, tw) { av.x += tv[0].x + tw[0].x; }
 #else
@@ -249,9 +256,16 @@ __global__ __launch_bounds__(64 * NW, SEP_WPS) void sepconv_mfma_kernel(SepArgs 
         av.z = fmaf(tv[u].z, tw[u].z, av.z); av.w = fmaf(tv[u].w, tw[u].w, av.w);                               \
     }
 #endif
+#ifdef SEP_ABL_NORB       // timing ablation: no B reads
+#define SEP_RB(st, bq, g, e) _Pragma("unroll") for (int jn = 0; jn < 4; jn++) bq[jn] = 1.0f + jn + e;
+#else
+#define SEP_RB_REAL 1
+#endif
+#ifdef SEP_RB_REAL
 #define SEP_RB(st, bq, g, e)                                                                                    \
     _Pragma("unroll") for (int jn = 0; jn < 4; jn++)                                                            \
         bq[jn] = *reinterpret_cast<const float *>(st + boff + (((8 * g + e) * 128) + 32 * jn) * 4);
+#endif
 #ifdef SEP_ABL_NOMFMA     // timing ablations only (wrong results): no MFMAs / no depthwise FMAs / no DMA
 #define SEP_MM(aval, bq) _Pragma("unroll") for (int jn = 0; jn < 4; jn++) acc[jn][0] += aval * bq[jn];
 #else
