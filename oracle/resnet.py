@@ -16,7 +16,6 @@ in float32 numpy with multiply and add kept separate, in the order csrc/resnet_k
 from __future__ import annotations
 
 import ctypes
-import math
 
 import numpy as np
 

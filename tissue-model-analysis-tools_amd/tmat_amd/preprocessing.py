@@ -11,7 +11,6 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import _lib
 from ._lib import Handle, check, lib, ptr
 
 

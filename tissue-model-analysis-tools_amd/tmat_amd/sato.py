@@ -16,7 +16,6 @@ import math
 
 import numpy as np
 
-from . import _lib
 from ._lib import Handle, Row, VesselStages, check, lib, ptr
 
 SATO_SIGMAS = (1, 2, 3, 4, 5, 7, 9, 11, 13, 15)            # compute_branches.py:262

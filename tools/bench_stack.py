@@ -13,7 +13,6 @@ import sys
 import time
 from pathlib import Path
 
-import numpy as np
 
 REPO = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(REPO))

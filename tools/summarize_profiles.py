@@ -3,7 +3,6 @@
 the rocprofv3 --kernel-trace --stats table, the bench lines, and a JSON summary with the dominant kernel's
 average duration and its per-launch HBM traffic from the PMC passes (FETCH_SIZE doubled as
 MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as read; both are in KiB)."""
-import collections
 import csv
 import json
 import shutil
