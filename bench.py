@@ -110,6 +110,18 @@ def cpu_baseline(img, weights, handle, log, n_sample_patches=40, repeats=3):
             "unet_seconds_per_image_oracle_c": round(t_unet_exact, 2), "count": int(n0)}
 
 
+class _StubHandle:
+    """TMAT_BENCH_STUB=1: the handle methods bench.py calls, without a GPU"""
+    def prof_enable(self, on):
+        pass
+
+    def prof_read(self, reset=False):
+        return 0.0, 0, 0.0
+
+    def close(self):
+        pass
+
+
 def _gen_image(i):
     from tmat_amd import synth
     return synth.synth_image(i, SIZE)
@@ -138,6 +150,8 @@ def main():
     except AttributeError:
         ncpu = os.cpu_count() or 8
     os.environ.setdefault("TMAT_HOST_THREADS", str(max(1, min(ncpu // max(1, world), 32))))      # = distributed.host_threads_per_rank
+    # the CPU baseline gets the same core share as the GPU path's host stages (oracle/unet.py:usable_cores reads this)
+    os.environ.setdefault("TMAT_ORACLE_THREADS", os.environ["TMAT_HOST_THREADS"])
 
     # synthetic inputs (image i of rank r from RandomState(1234 + r * 100003 + i)), generated by a process pool
     # BEFORE anything touches the GPU (fork after HIP initialisation is not safe)
@@ -147,43 +161,67 @@ def main():
     workers = max(1, min(ncpu // max(1, world), 32, n_distinct))
     if workers > 1:
         import multiprocessing as mp
-        with mp.get_context("fork").Pool(workers) as pool:
+        # close() + join(), not the context manager: its exit calls terminate(), which SIGTERMs the workers -- under rocprofv3
+        # every forked worker carries the profiler's signal handler and logs that as an abort
+        pool = mp.get_context("fork").Pool(workers)
+        try:
             distinct = pool.map(_gen_image, [rank * 100003 + i for i in range(n_distinct)], chunksize=1)
+        finally:
+            pool.close()
+            pool.join()
     else:
         distinct = [_gen_image(rank * 100003 + i) for i in range(n_distinct)]
     t_gen = time.perf_counter() - t_gen
 
     import torch
+    # TMAT_BENCH_STUB=1 (tests/test_bench_multirank.py): no GPU and no library -- a stand-in analyser computes the rows from the
+    # pixels on the CPU, the process group is gloo, and everything AROUND the hot path (sharding, barriers, the max-over-ranks
+    # of the elapsed time, the row all-gather, the JSON line) runs exactly as it does on GPUs.  Its number is not a measurement.
+    stub = os.environ.get("TMAT_BENCH_STUB") == "1"
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from tmat_amd import _lib, branches, synth
+    from tmat_amd import branches, synth
 
-    weights = synth.synth_weights(0)
-    handle = _lib.Handle(synth.pack_weights(weights), local_rank, args.max_patches)
-    L = _lib.lib()
-
-    # resident in HBM before the timed region (each rank has its own images)
     host = np.stack([distinct[i % len(distinct)] for i in range(n_img)])
-    dptr = ctypes.c_void_p()
-    _lib.check(L.tmat_dev_alloc(handle.raw, host.nbytes, ctypes.byref(dptr)), "dev_alloc")
-    _lib.check(L.tmat_dev_upload(handle.raw, dptr, _lib.ptr(host), host.nbytes), "dev_upload")
+    if stub:
+        weights = None
+        handle = _StubHandle()
+        dptr = L = None
 
-    def step():
-        return branches.analyze_batch(handle, (n_img, SIZE, SIZE), CFG, IMAGE_WIDTH_MICRONS, first_index=rank * n_img,
-                                      dev_ptr=dptr.value)
+        def step(n=n_img):
+            return [(rank * n_img + i, int(host[i].sum() % 97), float(host[i].mean()), float(host[i].std())) for i in range(n)]
+
+        def handle_sync():
+            pass
+    else:
+        from tmat_amd import _lib
+        weights = synth.synth_weights(0)
+        handle = _lib.Handle(synth.pack_weights(weights), local_rank, args.max_patches)
+        L = _lib.lib()
+        # resident in HBM before the timed region (each rank has its own images)
+        dptr = ctypes.c_void_p()
+        _lib.check(L.tmat_dev_alloc(handle.raw, host.nbytes, ctypes.byref(dptr)), "dev_alloc")
+        _lib.check(L.tmat_dev_upload(handle.raw, dptr, _lib.ptr(host), host.nbytes), "dev_upload")
+
+        def step(n=n_img):
+            return branches.analyze_batch(handle, (n, SIZE, SIZE), CFG, IMAGE_WIDTH_MICRONS, first_index=rank * n_img,
+                                          dev_ptr=dptr.value)
+
+        def handle_sync():
+            _lib.check(L.tmat_sync(handle.raw), "sync")
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize() if torch.cuda.is_available() else None
         handle_sync()
-
-    def handle_sync():
-        _lib.check(L.tmat_sync(handle.raw), "sync")
 
     def log(msg):
         if rank == 0:
@@ -207,7 +245,7 @@ def main():
     n_prof = min(16, n_img)
     handle.prof_enable(True)
     handle.prof_read(True)
-    prof_rows = branches.analyze_batch(handle, (n_prof, SIZE, SIZE), CFG, IMAGE_WIDTH_MICRONS, first_index=rank * n_img, dev_ptr=dptr.value)
+    prof_rows = step(n_prof)
     conv_ms, conv_launches, conv_flops = handle.prof_read(True)
     handle.prof_enable(False)
     for i in range(n_prof):
@@ -219,7 +257,7 @@ def main():
             raise SystemExit(f"bench: image {i} and its copy {i % nd} produced different rows: {r} vs {rows[i % nd]}")
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if stub else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # the one collective of the path: a single fixed-size all-gather of the 32-byte result rows over RCCL/xGMI
@@ -237,11 +275,13 @@ def main():
         # rocprofv3 --pmc passes, tools/profile_round.sh); it is per launch of 1600 patches, like `achieved`
         traffic = None
         top_by_time = None
+        traffic_source = None
         summ = sorted((REPO / "profiles").glob("r*_summary.json"))
-        if summ and args.max_patches == 1600:
+        if summ and args.max_patches == 1600 and not stub:
             sj = json.loads(summ[-1].read_text())
             traffic = sj.get("traffic_bytes_per_launch")
             top_by_time = sj.get("top_kernels_by_total_time")
+            traffic_source = f"profiles/{summ[-1].name} (committed rocprofv3 --pmc / --kernel-trace passes of this command; not re-measured in this run)"
         # path-level figure: every FLOP the step runs on the matrix cores (all 3x3 / sub-pixel / 1x1 layers) over the
         # whole step time (which also holds the vector-ALU layers, morphology, blending and the host stages)
         path_flops = synth.mfma_flops_per_patch() * 200.0 * n_img * world * args.steps
@@ -257,24 +297,27 @@ def main():
                        "images_per_gpu": n_img, "distinct_images": len(distinct), "patches_per_image": 200,
                        "rows_gathered": n_rows, "copies_identical": True, "host_threads": int(os.environ["TMAT_HOST_THREADS"])},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "tmat::conv_mfma_kernel<128, 128, 4, 2, 3, false> (3x3 implicit-GEMM on v_mfma_f32_32x32x2_f32; "
                                    "3 of the 8 transposed-conv layers, 39 % of the 3x3 / sub-pixel MFMA FLOPs; the largest kernel by total time)",
                          "launches": int(conv_launches), "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
                          "timed_in": f"separate pass of {n_prof} images after the timed region (HIP events on the launch stream)",
                          "path_achieved": round(path_tflops, 2), "path_frac": round(path_tflops / MFMA_F32_PEAK_TFLOPS, 4),
                          "path_note": "executed MFMA FLOPs of the whole step (19.08 GFLOP/patch: every 3x3 / sub-pixel / 1x1 layer) / ms_per_step, per GPU",
-                         "top_kernels_by_total_time": top_by_time},
+                         "top_kernels_by_total_time": top_by_time, "top_kernels_source": traffic_source},
         }
         sample = [r for r in rows[:4]]
         out["config"]["sample_rows"] = [[int(r[0]), int(r[1]), round(r[2], 3)] for r in sample]
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not stub:
         out["cpu_baseline"] = cpu_baseline(host[0], weights, handle, log)
     elif rank == 0:
         out["cpu_baseline"] = None
+    if rank == 0 and stub:
+        out["data"] = "synthetic (TMAT_BENCH_STUB: stand-in analyser on the CPU, not a measurement)"
 
-    _lib.check(L.tmat_dev_free(handle.raw, dptr), "dev_free")
+    if not stub:
+        _lib.check(L.tmat_dev_free(handle.raw, dptr), "dev_free")
     handle.close()
     if dist is not None:
         dist.barrier()

@@ -625,6 +625,16 @@ __global__ __launch_bounds__(256) void pool_fix_add_kernel(float *__restrict__ o
     *reinterpret_cast<float4 *>(out + o) = m;
 }
 
+// finishes the tile edges of a pooled separable convolution (tiles of 2 nw rows x 16 columns; Cout / 4 a power of two)
+void launch_pool_fix_add(float *out, const float *sh, const float *sv, const float *co, const float *resid, int N, int H, int W, int Cout, int nw,
+                         hipStream_t s)
+{
+    int c4shift = 0;
+    while ((1 << c4shift) < Cout / 4) c4shift++;
+    const int total = (H / (2 * nw)) * (W / 16) * (8 + nw - 1) * (Cout / 4);
+    hipLaunchKernelGGL(pool_fix_add_kernel, dim3((total + 255) / 256, N), dim3(256), 0, s, out, sh, sv, co, resid, H / 2, W / 2, Cout, c4shift, total, nw);
+}
+
 size_t sepconv_pool_scratch_floats(int N, int H, int W, int Cout)
 {
     return (size_t)N * (H / 8) * (W / 16) * 17 * Cout;           // strips: 8 + PR + 1 pixels per tile, sized for the smaller tile
@@ -644,12 +654,9 @@ bool launch_sepconv_pool(const float *in, int N, int H, int W, int Cin, int relu
     const size_t tiles = (size_t)N * (H / (2 * nw)) * (W / 16);
     float *sh = scratch, *sv = sh + tiles * 8 * Cout, *co = sv + tiles * nw * Cout;
     SepArgs a{in, N, H, W, Cin, Cout, dwq, pw, scale, shift, relu_out, out, resid, sh, sv, co, nullptr};
+    if ((Cout / 4) & (Cout / 4 - 1)) { set_error("launch_sepconv_pool: Cout / 4 must be a power of two"); return false; }
     launch_sep_any<true>(a, relu_in, nw, s);
-    int c4shift = 0;
-    while ((1 << c4shift) < Cout / 4) c4shift++;
-    if ((1 << c4shift) != Cout / 4) { set_error("launch_sepconv_pool: Cout / 4 must be a power of two"); return false; }
-    const int total = (H / (2 * nw)) * (W / 16) * (8 + nw - 1) * (Cout / 4);
-    hipLaunchKernelGGL(pool_fix_add_kernel, dim3((total + 255) / 256, N), dim3(256), 0, s, out, sh, sv, co, resid, H / 2, W / 2, Cout, c4shift, total, nw);
+    launch_pool_fix_add(out, sh, sv, co, resid, N, H, W, Cout, nw, s);
     return true;
 }
 

@@ -1,0 +1,547 @@
+// Fused SeparableConv2D, wave-specialised form (round 3) for gfx950 (MI355X).  NHWC float32.
+//
+// Reference graph: fl_tissue_model_tools/models.py:126-144 (SeparableConv2D + BatchNormalization pairs of every down
+// block, MaxPooling2D(3, 2, "same") + residual add behind the second one), executed by keras Model.predict at
+// smooth_tiled_predictions.py:179.
+//
+// sepconv_kernels.hip computes the depthwise values inside the MFMA waves (each lane builds its own A fragment between
+// its MFMAs); its counters show the matrix pipe busy 0.53-0.65 of the time: the in-order waves cannot overlap their own
+// vector work, LDS reads and LDS-DMA issue with their own MFMAs.  Here the two kinds of work live in DIFFERENT waves of
+// one 12-wave workgroup, which the four SIMDs of a CU run side by side (the matrix pipe and the vector ALU of a SIMD
+// issue from different waves in the same cycles):
+//   waves 0-7  consumers: a 16 x 16 pixel tile (M = 256) x 128 output channels on v_mfma_f32_32x32x2_f32; wave w owns
+//              tile rows 2w, 2w+1 as four 32x32 accumulators.  Per 32-channel step: 20 ds_read_b128, 64 MFMAs, one
+//              barrier.  No vector-memory instruction except the tile's stores.
+//   waves 8-11 producers: wave p owns the 8 x 8 pixel quadrant (p >> 1, p & 1) of the tile.  Per step it (1) waits for
+//              ITS OWN 10 x 10 pixel halo of the next step's 32 channels (LDS-DMA into a private LDS region: no other
+//              wave reads it, so no barrier orders it, only the wave's own vmcnt), (2) slides a 3 x 3 register window
+//              down its column (lane = channel quad x column: 3 ds_read_b128 and 36 FMAs per output quad), (3) writes
+//              the depthwise values as the NEXT step's A operand, [MFMA row][32 channels] with the convolution kernel's
+//              bank swizzle, (4) issues the LDS-DMA of the next step's pointwise weights and of its own next halo.
+// Two A / B stages; the halo region is single (a producer refills it after its last read of the step).
+//
+// Arithmetic contract: identical to sepconv_kernels.hip and to oracle/unet_exact.c:orc_dwconv -> orc_conv (depthwise
+// chain over the 9 taps in (ky, kx) order from +0.0, zero padding, optional ReLU on load; pointwise chain over the
+// input channels in groups of 8 in the order 0,4,1,5,2,6,3,7; epilogue fmaf(acc, scale, shift), optional ReLU; the
+// pooled form: max, then one add).  tests/test_gpu_unet.py compares bits.
+#include "tmat_internal.h"
+#include "../../include/tmat.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace tmat {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// LDS map (floats): [A0 | X | A1 | B0 | B1 | H0 H1 H2 H3].  The pooling epilogue's exchange buffer (9216 floats) lies over
+// the A stage the tile's last step has just consumed plus the gap X: [A0 | X] or [X | A1].
+constexpr int WS_A = 256 * 32, WS_X = 1024, WS_B = 128 * 32, WS_NHP = 13, WS_HP = WS_NHP * 256;
+constexpr int WS_A0 = 0, WS_A1 = WS_A + WS_X, WS_B0 = WS_A1 + WS_A, WS_B1 = WS_B0 + WS_B, WS_H = WS_B1 + WS_B;
+constexpr int WS_TOTAL = WS_H + 4 * WS_HP;          // 38 912 floats = 152 KiB
+static_assert(WS_TOTAL * 4 <= 160 * 1024, "LDS budget");
+static_assert(8 * 9 * 128 <= WS_A + WS_X, "exchange buffer fits an A stage + gap");
+
+struct WsArgs {
+    const float *in;      // (N, H, W, Cin)
+    int N, H, W, Cin, Cout;
+    const float *dw9;     // depthwise taps [9][Cin] (the Keras layout)
+    const float *pwk;     // pointwise weights [Cout][Cin] (k contiguous)
+    const float *scale, *shift;
+    int relu_out;
+    float *out;           // (N, H, W, Cout); POOL: (N, H/2, W/2, Cout), see sepconv_kernels.hip:SepArgs
+    const float *resid;   // POOL only
+    float *strip_h, *strip_v, *corner;      // POOL only (pool_fix_add_kernel finishes the tile edges)
+};
+
+__device__ __forceinline__ int ws_pixmap_y(int r) { return ((r >= 4 && r < 12) || (r >= 16 && r < 20) || r >= 28) ? 1 : 0; }
+__device__ __forceinline__ int ws_pixmap_x(int r) { return r < 4 ? r : r < 12 ? r - 4 : r < 16 ? r - 8 : r < 20 ? r - 8 : r < 28 ? r - 12 : r - 16; }
+
+// workgroup barrier that leaves LDS-DMA in flight (no vmcnt wait: __syncthreads() would drain it)
+#define WS_BAR() { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+#define WS_PIN() __builtin_amdgcn_sched_barrier(0);
+#ifdef WS_DIAG            // diagnostic build (tools/build_variant.sh): s_memtime stamps at the phase boundaries, summed per wave
+__device__ long long ws_diag[256 * 12 * 8];
+#define WS_STAMP(k) { const long long now_ = (long long)__builtin_readcyclecounter(); dsum[k] += now_ - dlast; dlast = now_; }
+#define WS_DIAG_DECL long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = (long long)__builtin_readcyclecounter();
+#define WS_DIAG_FLUSH() if (lane == 0 && blockIdx.x < 256) { for (int k = 0; k < 8; k++) ws_diag[((size_t)blockIdx.x * 12 + wave) * 8 + k] = dsum[k]; }
+#else
+#define WS_STAMP(k)
+#define WS_DIAG_DECL
+#define WS_DIAG_FLUSH()
+#endif
+
+template <bool RELU_IN, bool POOL>
+__global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, int nNt, int G)
+{
+    __shared__ __attribute__((aligned(16))) float smem[WS_TOTAL];
+
+    // persistent ranges as in sepconv_mfma_kernel: an XCD gets a contiguous super-range of the (pixel tile, channel tile) pairs
+    const int b = blockIdx.x;
+    const int bp = (b & 7) * (G >> 3) + (b >> 3);
+    const long long P = (long long)nMt * nNt;
+    const int j0 = (int)(P * bp / G), j1 = (int)(P * (bp + 1) / G);
+    if (j0 >= j1) return;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int TW = a.W >> 4, TPP = (a.H >> 4) * TW;          // tiles per row / per patch
+    const int Cin = a.Cin;
+    const int nchunks = Cin >> 5;
+    const int total = (j1 - j0) * nchunks;                   // steps of this workgroup
+    constexpr unsigned OOB = 0x80000000u;
+
+    if (wave >= 8) {
+        // ================================ producer ================================
+        const int p = wave - 8;
+#ifndef WS_PRODUCER_PRIO
+#define WS_PRODUCER_PRIO 3
+#endif
+        // The producers are the youngest waves of their SIMDs and would lose every issue arbitration against the two MFMA
+        // waves (priority, then age): at equal priority their vector instructions issued once per ~32 cycles.
+        __builtin_amdgcn_s_setprio(WS_PRODUCER_PRIO);
+        const int oy = (p >> 1) * 8, ox = (p & 1) * 8;
+        float *Hp = smem + WS_H + p * WS_HP;
+        const int q = lane & 7, xl = lane >> 3;
+        // A rows of this lane's column: MFMA row r of consumer wave (oy + y) >> 1, r = PIXMAP^-1(y & 1, ox + xl)
+        const int Xt = ox + xl;
+        const int r0 = Xt < 4 ? Xt : Xt < 8 ? Xt + 8 : Xt + 12;
+        const int r1 = Xt < 8 ? Xt + 4 : Xt < 12 ? Xt + 8 : Xt + 16;
+        const int aoff0 = ((oy >> 1) * 32 + r0) * 32 + ((q ^ ((r0 >> 1) & 7)) * 4);
+        const int aoff1 = ((oy >> 1) * 32 + r1) * 32 + ((q ^ ((r1 >> 1) & 7)) * 4);
+        const int hoff = xl * 32 + q * 4;                    // halo pixel (hy, xl + dx): + (hy * 10 + dx) * 32
+        // B pieces 4p .. 4p+3 (8 weight rows of 128 B each): row 32p + 8i + (lane >> 3), 16-byte slot lane & 7 holds the
+        // channel group (lane & 7) ^ ((row >> 1) & 7) = (lane & 7) ^ ((4i + (lane >> 4)) & 7)
+        const unsigned bvo0 = (unsigned)((32 * p + (lane >> 3)) * Cin * 4 + (((lane & 7) ^ (lane >> 4)) * 16));
+        const unsigned bvo1 = (unsigned)((32 * p + 8 + (lane >> 3)) * Cin * 4 + (((lane & 7) ^ (4 + (lane >> 4))) * 16));
+
+        // Halo addressing.  Piece i of the 13 LDS-DMA pieces carries halo pixels 8i .. 8i+7 (hp = 8i + (lane >> 3), row hp / 10,
+        // column hp % 10 of the 10 x 10 halo), 16 bytes of channel quad lane & 7 per lane.  rel[i] is the lane's byte offset from
+        // the halo's first pixel (tile independent); per tile only the buffer base moves and the pieces that fall outside the
+        // image are redirected to an out-of-range offset (the buffer range check then returns the zeros of the padding).
+        // tile_setup is pure vector arithmetic, so it runs in the vector phase (see below), never next to the consumers' MFMAs.
+        unsigned rel[WS_NHP], hv[WS_NHP];
+        unsigned m_top = 0, m_bot = 0, m_left = 0, m_right = 0, m_inv = 0;      // bit i: piece i of this lane lies in halo row 0 / row 9 / column 0 / column 9 / past the halo
+#pragma unroll
+        for (int i = 0; i < WS_NHP; i++) {
+            const int hp = 8 * i + (lane >> 3);
+            const int hy = hp / 10, hx = hp - hy * 10;
+            rel[i] = (unsigned)((hy * a.W + hx) * Cin + (lane & 7) * 4) * 4u;
+            m_top |= (unsigned)(hy == 0) << i; m_bot |= (unsigned)(hy == 9) << i;
+            m_left |= (unsigned)(hx == 0) << i; m_right |= (unsigned)(hx == 9) << i;
+            m_inv |= (unsigned)(hp >= 100) << i;
+        }
+        const float *hA = a.in;
+        auto tile_setup = [&](int jj) {
+            const int mt = jj / nNt;
+            const int n = mt / TPP, tr = mt - n * TPP;
+            const int Y0 = (tr / TW) * 16 + oy - 1, X0 = (tr % TW) * 16 + ox - 1;      // image position of the halo's first pixel
+            hA = a.in + ((long)n * a.H * a.W + (long)Y0 * a.W + X0) * Cin;             // may lie before the tensor for border tiles: those lanes are masked
+            const unsigned bad = m_inv | (Y0 < 0 ? m_top : 0u) | (Y0 + 9 >= a.H ? m_bot : 0u) | (X0 < 0 ? m_left : 0u) | (X0 + 9 >= a.W ? m_right : 0u);
+#pragma unroll
+            for (int i = 0; i < WS_NHP; i++) hv[i] = ((bad >> i) & 1u) ? OOB : rel[i];
+        };
+        int hj = j0, hc = 0;                                 // next halo to load: (pair, chunk)
+        auto issue_halo = [&]() {
+            const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)hA, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < WS_NHP; i++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t *)(Hp + i * 256), 16, hv[i], hc * 128, 0, 0);
+            if (++hc == nchunks) { hc = 0; hj++; }
+        };
+        WS_DIAG_DECL
+        int pj = j0, pc = 0;                                 // step being produced: (pair, chunk)
+        float4 wt[9];                                        // its depthwise taps
+        const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc((void *)a.dw9, 0, 0x7fffffff, 0x00020000);
+        auto load_taps = [&]() {                             // buffer loads: per-lane offset fixed, (tap, chunk) in the scalar offset -- no vector arithmetic
+#pragma unroll
+            for (int tp = 0; tp < 9; tp++)
+                wt[tp] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsT, q * 16, (tp * Cin + pc * 32) * 4, 0));
+        };
+        // The f32 MFMA and the vector ALU do not run side by side on a SIMD: next to two consumer waves that keep the matrix
+        // pipe full, a producer's FMAs issued once per 20-40 cycles whatever its priority (measured: 6 000-10 000 cycles for
+        // the 290-410 vector instructions of a step, the consumers waiting at the barrier for half of that).  So a step has
+        // two phases separated by workgroup barriers:
+        //   MFMA phase   consumers: the step's 64 MFMAs each.  Producers: everything that is NOT vector arithmetic for the
+        //                next step -- LDS-DMA of its halo, taps and pointwise weights, the wait for them, the first four halo
+        //                rows into registers.
+        //   vector phase producers: the next step's depthwise values (dense: nothing else wants the pipe).  Consumers: at
+        //                a tile's last step the epilogue (also vector work + stores), otherwise nothing.
+        float4 win[4][3];                                    // halo rows y .. y+3 of this lane's column
+        auto load_row = [&](int hy, float4 *row) {
+            const float *hb = Hp + hoff;
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) row[dx] = *reinterpret_cast<const float4 *>(hb + (hy * 10 + dx) * 32);
+        };
+        auto relu_row = [&](float4 *row) {
+            if (RELU_IN) {
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++) {
+                    row[dx].x = fmaxf(row[dx].x, 0.f); row[dx].y = fmaxf(row[dx].y, 0.f);
+                    row[dx].z = fmaxf(row[dx].z, 0.f); row[dx].w = fmaxf(row[dx].w, 0.f);
+                }
+            }
+        };
+        auto fetch = [&](int stage) {
+            load_taps();
+            issue_halo();
+            {
+                const int nt = pj % nNt;
+                float *Bs = smem + (stage ? WS_B1 : WS_B0);
+                const __amdgpu_buffer_rsrc_t rsB =
+                    __builtin_amdgcn_make_buffer_rsrc((void *)(a.pwk + (size_t)nt * 128 * Cin), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t *)(Bs + (4 * p + i) * 256), 16,
+                                                             (i & 1) ? bvo1 : bvo0, pc * 128 + (i >> 1) * 16 * Cin * 4, 0, 0);
+            }
+            if (++pc == nchunks) { pc = 0; pj++; }
+            WS_STAMP(0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // taps, halo, weights: all landed before the phase ends
+            WS_STAMP(1)
+            load_row(0, win[0]);
+            load_row(1, win[1]);
+            load_row(2, win[2]);
+            load_row(3, win[3]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            WS_STAMP(2)
+        };
+        auto compute = [&](int stage) {
+            float *As = smem + (stage ? WS_A1 : WS_A0);
+#pragma unroll
+            for (int y = 0; y < 8; y += 2) {
+                if (y) {
+                    load_row(y + 2, win[(y + 2) & 3]);
+                    load_row(y + 3, win[(y + 3) & 3]);
+                }
+                WS_PIN()
+                if (y == 0) { relu_row(win[0]); relu_row(win[1]); }
+                relu_row(win[(y + 2) & 3]);
+                relu_row(win[(y + 3) & 3]);
+                float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+#pragma unroll
+                for (int tp = 0; tp < 9; tp++) {
+                    const float4 v0 = win[(y + tp / 3) & 3][tp % 3], v1 = win[(y + 1 + tp / 3) & 3][tp % 3];
+                    acc0.x = fmaf(v0.x, wt[tp].x, acc0.x); acc0.y = fmaf(v0.y, wt[tp].y, acc0.y);
+                    acc0.z = fmaf(v0.z, wt[tp].z, acc0.z); acc0.w = fmaf(v0.w, wt[tp].w, acc0.w);
+                    acc1.x = fmaf(v1.x, wt[tp].x, acc1.x); acc1.y = fmaf(v1.y, wt[tp].y, acc1.y);
+                    acc1.z = fmaf(v1.z, wt[tp].z, acc1.z); acc1.w = fmaf(v1.w, wt[tp].w, acc1.w);
+                }
+                *reinterpret_cast<float4 *>(As + aoff0 + (y >> 1) * 1024) = acc0;
+                *reinterpret_cast<float4 *>(As + aoff1 + (y >> 1) * 1024) = acc1;
+                WS_PIN()
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // A written (and the halo reads done: the next fetch refills it)
+            if (hc == 0 && hj < j1) tile_setup(hj);                   // the next fetch starts a new tile
+        };
+
+        tile_setup(j0);
+        fetch(0);
+        compute(0);
+        WS_BAR()
+        int cc = 0;
+        for (int s = 0; s < total; s++) {
+            if (s + 1 < total) fetch((s + 1) & 1);
+            WS_STAMP(3)
+            WS_BAR()                                         // consumers: MFMAs of step s issued
+            WS_STAMP(4)
+            if (s + 1 < total) compute((s + 1) & 1);
+            WS_STAMP(5)
+            if (++cc == nchunks) {
+                cc = 0;
+                if (POOL) WS_BAR()                           // inside the consumers' pooling epilogue
+            }
+            WS_BAR()                                         // step s + 1's operands are in LDS
+            WS_STAMP(6)
+        }
+#ifdef WS_DIAG
+        dsum[7] = total;
+#endif
+        WS_DIAG_FLUSH()
+        return;
+    }
+
+    // ================================ consumers ================================
+    const int r = lane & 31, h = lane >> 5;
+    const int key = (r >> 1) & 7;
+    const int aoffc = (32 * wave + r) * 32, boffc = r * 32;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int jn = 0; jn < 4; jn++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[jn][e] = 0.f;
+
+    // Folded-BN scale / shift of this lane's 4 output channels and (POOL) the residual values of its pooled pixels are loaded
+    // BEFORE the MFMAs of a tile's steps, never inside the epilogue: a load there is followed by s_waitcnt vmcnt(0), which
+    // also waits for every store the wave has in flight -- the epilogue would drain its own stores four times per tile
+    // instead of leaving them to complete under the next tile's MFMAs.
+    float scv[4], shv[4];
+    auto load_scale_shift = [&](int jj) {
+        const int n0 = (jj % nNt) * 128;
+#pragma unroll
+        for (int jn = 0; jn < 4; jn++) { scv[jn] = a.scale[n0 + jn * 32 + r]; shv[jn] = a.shift[n0 + jn * 32 + r]; }
+    };
+    // Epilogue addressing without vector arithmetic: buffer loads / stores whose per-lane offset is a kernel constant (this
+    // lane's channel and tile row), the tile in the buffer base and (pixel, channel group) in the scalar offset -- in the
+    // vector phase every vector instruction of the 8 consumer waves delays the producers' depthwise arithmetic and vice versa.
+    const int CoutB = a.Cout * 4;
+    const unsigned vo_pool = (unsigned)(4 * h * a.Cout + r) * 4u;        // pooled pixel 4h (+ q), channel r (+ 32 jn)
+    float rv[4][4];
+    auto load_resid = [&](int jj) {
+        const int mt = jj / nNt, nt = jj - mt * nNt;
+        const int n = mt / TPP, tr = mt - n * TPP;
+        const int ty = tr / TW, tx = tr - ty * TW;
+        const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(a.resid + (((size_t)n * (a.H >> 1) + ty * 8 + wave) * (a.W >> 1) + tx * 8) * a.Cout + nt * 128), 0, 0x7fffffff, 0x00020000);
+        if (wave < 7) {             // the tile's last pooled row is finished (and gets its residual) in pool_fix_add_kernel
+#pragma unroll
+            for (int jn = 0; jn < 4; jn++)
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++)      // h = 1, q = 3 is column 7 (finished in pool_fix_add_kernel too): loaded but not used
+                    rv[jn][qq] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, vo_pool, qq * CoutB + jn * 128, 0));
+        }
+    };
+
+    // ---- epilogue of one tile: straight from the accumulators (C/D layout: column = lane & 31 = output channel, row
+    // rho = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) = the MFMA row, i.e. PIXMAP's r)
+    // register e of a 32x32 accumulator is MFMA row rho = (e & 3) + 8 (e >> 2) + 4 h = tile pixel (y, x) with x = e and
+    // y = h for e in {0-3, 12-15}, 1 - h for e in 4..11 (PIXMAP): two per-lane offsets, everything else scalar
+    const unsigned vo_y0 = (unsigned)(h * a.W * a.Cout + r) * 4u, vo_y1 = (unsigned)((1 - h) * a.W * a.Cout + r) * 4u;
+    auto store_tile = [&](int jj) {
+        const int mt = jj / nNt, nt = jj - mt * nNt;
+        const int n = mt / TPP, tr = mt - n * TPP;
+        const int ty0 = (tr / TW) * 16, tx0 = (tr % TW) * 16;
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(a.out + ((size_t)n * a.H * a.W + (size_t)(ty0 + 2 * wave) * a.W + tx0) * a.Cout + nt * 128), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int jn = 0; jn < 4; jn++) {
+            const float sc = scv[jn], sh = shv[jn];
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                float v = fmaf(acc[jn][e], sc, sh);
+                if (a.relu_out) v = fmaxf(v, 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsO, (e >= 4 && e < 12) ? vo_y1 : vo_y0, e * CoutB + jn * 128, 0);
+                acc[jn][e] = 0.f;
+            }
+        }
+    };
+
+    // ---- POOL epilogue (see sepconv_kernels.hip:store_tile_pool for the derivation): MaxPooling2D(3, 2, "same") of the
+    // tile from the accumulators; row 2w + 2 comes from wave w + 1 through the exchange buffer
+    auto store_tile_pool = [&](int jj, float *xch) {
+        constexpr int NW = 8, XC = 128;
+        const int mt = jj / nNt, nt = jj - mt * nNt;
+        const int n = mt / TPP, tr = mt - n * TPP;
+        const int ty = tr / TW, tx = tr - ty * TW;
+        const int n0 = nt * 128;
+        const size_t T = (size_t)n * TPP + tr;
+        float hm[4][4], vs[4];
+        constexpr float NEG = -__builtin_inff();
+        const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)(a.out + (((size_t)n * (a.H >> 1) + ty * NW + wave) * (a.W >> 1) + tx * 8) * a.Cout + n0), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsSH = __builtin_amdgcn_make_buffer_rsrc((void *)(a.strip_h + T * 8 * a.Cout + n0), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsSV = __builtin_amdgcn_make_buffer_rsrc((void *)(a.strip_v + (T * NW + wave) * a.Cout + n0), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsCO = __builtin_amdgcn_make_buffer_rsrc((void *)(a.corner + T * a.Cout + n0), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int jn = 0; jn < 4; jn++) {
+            const float sc = scv[jn], sh = shv[jn];
+            float v[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                v[e] = fmaf(acc[jn][e], sc, sh);
+                if (a.relu_out) v[e] = fmaxf(v[e], 0.f);
+                acc[jn][e] = 0.f;
+            }
+            // columns 8 h + k, k = 0..7: own register 8 h + k; the other half wave's register of the same index holds the other
+            // tile row.  (v_permlane32_swap_b32 would do the exchange in one vector instruction; with this register reuse pattern
+            // the ROCm 7.2 builtin produced wrong values although tools/dev/permlane_probe.hip shows the documented semantics.)
+            float y0[9], y1[9];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float own = h ? v[8 + k] : v[k];
+                const float oth = __shfl_xor(h ? v[k] : v[8 + k], 32);      // the other half sends what this one lacks
+                y0[k] = k < 4 ? own : oth;                   // quads 0, 2: this half holds y0; quads 1, 3: y1
+                y1[k] = k < 4 ? oth : own;
+            }
+            {   // column 8 h + 8: x = 8 for h = 0 (register 8: this half holds its y1, the other half its y0), none for h = 1
+                const float o8 = __shfl_xor(v[8], 32);
+                y0[8] = h ? NEG : o8;
+                y1[8] = h ? NEG : v[8];
+            }
+            float m01[9], h0[4];
+#pragma unroll
+            for (int k = 0; k < 9; k++) m01[k] = fmaxf(y0[k], y1[k]);
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                hm[jn][qq] = fmaxf(fmaxf(m01[2 * qq], m01[2 * qq + 1]), m01[2 * qq + 2]);
+                h0[qq] = fmaxf(fmaxf(y0[2 * qq], y0[2 * qq + 1]), y0[2 * qq + 2]);
+                xch[(wave * 9 + 4 * h + qq) * XC + jn * 32 + r] = h0[qq];
+                if (wave == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, h0[qq]), rsSH, vo_pool, qq * CoutB + jn * 128, 0);
+            }
+            vs[jn] = m01[0];
+            if (h == 0) {
+                xch[(wave * 9 + 8) * XC + jn * 32 + r] = y0[0];
+                if (wave == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y0[0]), rsCO, r * 4, jn * 128, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        WS_BAR()
+#pragma unroll
+        for (int jn = 0; jn < 4; jn++) {
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                float pv = hm[jn][qq];
+                if (wave < NW - 1) {
+                    pv = fmaxf(pv, xch[((wave + 1) * 9 + 4 * h + qq) * XC + jn * 32 + r]);
+                    if (qq < 3 || h == 0) pv = pv + rv[jn][qq];
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pv), rsP, vo_pool, qq * CoutB + jn * 128, 0);
+            }
+            if (h == 0) {
+                float cv = vs[jn];
+                if (wave < NW - 1) cv = fmaxf(cv, xch[((wave + 1) * 9 + 8) * XC + jn * 32 + r]);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, cv), rsSV, r * 4, jn * 128, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // exchange values read before the step's closing barrier
+    };
+
+    WS_DIAG_DECL
+    WS_BAR()                                                 // step 0's operands are in LDS
+    int cj = j0, cc = 0;
+    for (int s = 0; s < total; s++) {
+        const int stage = s & 1;
+        WS_STAMP(0)
+        if (cc == 0) load_scale_shift(cj);
+        if (POOL && cc == nchunks - 1) load_resid(cj);
+        const float *As = smem + (stage ? WS_A1 : WS_A0) + aoffc;
+        const float *Bs = smem + (stage ? WS_B1 : WS_B0) + boffc;
+        float4 av[2], bv[2][4];
+#define WS_READ(g)                                                                                              \
+        {                                                                                                       \
+            const int slot = (((2 * (g)) + h) ^ key) * 4;                                                       \
+            av[(g) & 1] = *reinterpret_cast<const float4 *>(As + slot);                                         \
+            _Pragma("unroll") for (int jn = 0; jn < 4; jn++) bv[(g) & 1][jn] = *reinterpret_cast<const float4 *>(Bs + jn * 1024 + slot); \
+        }
+#define WS_MM(g)                                                                                                \
+        {                                                                                                       \
+            _Pragma("unroll") for (int jn = 0; jn < 4; jn++) acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(g) & 1].x, bv[(g) & 1][jn].x, acc[jn], 0, 0, 0); \
+            _Pragma("unroll") for (int jn = 0; jn < 4; jn++) acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(g) & 1].y, bv[(g) & 1][jn].y, acc[jn], 0, 0, 0); \
+            _Pragma("unroll") for (int jn = 0; jn < 4; jn++) acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(g) & 1].z, bv[(g) & 1][jn].z, acc[jn], 0, 0, 0); \
+            _Pragma("unroll") for (int jn = 0; jn < 4; jn++) acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(g) & 1].w, bv[(g) & 1][jn].w, acc[jn], 0, 0, 0); \
+        }
+        WS_READ(0)
+        WS_PIN()
+        WS_READ(1)
+        WS_PIN()
+        WS_MM(0)
+        WS_PIN()
+        WS_READ(2)
+        WS_PIN()
+        WS_MM(1)
+        WS_PIN()
+        WS_READ(3)
+        WS_PIN()
+        WS_MM(2)
+        WS_PIN()
+        WS_MM(3)
+        WS_PIN()
+#undef WS_READ
+#undef WS_MM
+        WS_STAMP(1)
+        WS_BAR()                                             // vector phase: the producers compute the next step's A operand
+        WS_STAMP(2)
+        if (++cc == nchunks) {
+            cc = 0;
+            if (POOL) store_tile_pool(cj, smem + (stage ? WS_A : 0));
+            else store_tile(cj);
+            cj++;
+        }
+        WS_STAMP(3)
+        WS_BAR()
+        WS_STAMP(4)
+    }
+#ifdef WS_DIAG
+    dsum[7] = total;
+#endif
+    WS_DIAG_FLUSH()
+}
+
+bool sepconv_ws_supported(int H, int W, int Cin, int Cout)
+{
+    return H % 16 == 0 && W % 16 == 0 && Cin % 32 == 0 && Cout % 128 == 0 &&
+           (long long)H * W * Cin * 4 < 0x7fffffffLL && (long long)Cout * Cin * 4 < 0x7fffffffLL;
+}
+
+static int ws_cus()
+{
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 8) n_cu = 256;
+        else n_cu = prop.multiProcessorCount;
+    }
+    return n_cu;
+}
+
+template <bool POOL>
+static void launch_ws_any(const WsArgs &a, int relu_in, hipStream_t s)
+{
+    const int nMt = a.N * (a.H / 16) * (a.W / 16), nNt = a.Cout / 128;
+    const int G = (ws_cus() / 8) * 8;                       // one persistent 12-wave workgroup per CU (152 KiB of LDS)
+    if (relu_in) hipLaunchKernelGGL((sepconv_ws_kernel<true, POOL>), dim3(G), dim3(768), 0, s, a, nMt, nNt, G);
+    else hipLaunchKernelGGL((sepconv_ws_kernel<false, POOL>), dim3(G), dim3(768), 0, s, a, nMt, nNt, G);
+#ifdef WS_DIAG
+    {
+        static long long hbuf[256 * 12 * 8];
+        hipStreamSynchronize(s);
+        hipMemcpyFromSymbol(hbuf, HIP_SYMBOL(ws_diag), sizeof(hbuf));
+        double cs[8] = {0}, ps[8] = {0};
+        const int nb = G < 256 ? G : 256;
+        for (int b = 0; b < nb; b++)
+            for (int w = 0; w < 12; w++)
+                for (int k = 0; k < 8; k++) (w < 8 ? cs : ps)[k] += (double)hbuf[((size_t)b * 12 + w) * 8 + k];
+        const double cst = cs[7], pst = ps[7];
+        fprintf(stderr, "[wsdiag] H %d Cin %d Cout %d pool %d | consumer per step: top %.0f mfma %.0f barX %.0f epilogue %.0f barY %.0f | producer per step: issue %.0f vmcnt0 %.0f rows %.0f barX %.0f compute %.0f barY %.0f | steps/wave %.0f\n",
+                a.H, a.Cin, a.Cout, (int)POOL, cs[0] / cst, cs[1] / cst, cs[2] / cst, cs[3] / cst, cs[4] / cst,
+                ps[0] / pst, ps[1] / pst, ps[2] / pst, (ps[3] + ps[4]) / pst, ps[5] / pst, ps[6] / pst, cst / (nb * 8.0));
+    }
+#endif
+}
+
+bool launch_sepconv_ws(const float *in, int N, int H, int W, int Cin, int relu_in, const float *dw9, const float *pwk, int Cout,
+                       const float *scale, const float *shift, int relu_out, float *out, hipStream_t s)
+{
+    if (!sepconv_ws_supported(H, W, Cin, Cout) || N <= 0 || (long long)N * (H / 16) * (W / 16) * (Cout / 128) > 0x3fffffffLL) {
+        set_error("launch_sepconv_ws: unsupported shape");
+        return false;
+    }
+    WsArgs a{in, N, H, W, Cin, Cout, dw9, pwk, scale, shift, relu_out, out, nullptr, nullptr, nullptr, nullptr};
+    launch_ws_any<false>(a, relu_in, s);
+    return true;
+}
+
+// pool_fix_add_kernel lives in sepconv_kernels.hip; the strips have that kernel's 8-wave (16 x 16 tile) layout
+void launch_pool_fix_add(float *out, const float *sh, const float *sv, const float *co, const float *resid, int N, int H, int W, int Cout, int nw,
+                         hipStream_t s);
+
+bool launch_sepconv_pool_ws(const float *in, int N, int H, int W, int Cin, int relu_in, const float *dw9, const float *pwk, int Cout,
+                            const float *scale, const float *shift, int relu_out, float *scratch, const float *resid, float *out, hipStream_t s)
+{
+    if (!sepconv_ws_supported(H, W, Cin, Cout) || N <= 0 || (long long)N * (H / 16) * (W / 16) * (Cout / 128) > 0x3fffffffLL ||
+        ((Cout / 4) & (Cout / 4 - 1))) {
+        set_error("launch_sepconv_pool_ws: unsupported shape");
+        return false;
+    }
+    const size_t tiles = (size_t)N * (H / 16) * (W / 16);
+    float *sh = scratch, *sv = sh + tiles * 8 * Cout, *co = sv + tiles * 8 * Cout;
+    WsArgs a{in, N, H, W, Cin, Cout, dw9, pwk, scale, shift, relu_out, out, resid, sh, sv, co};
+    launch_ws_any<true>(a, relu_in, s);
+    launch_pool_fix_add(out, sh, sv, co, resid, N, H, W, Cout, 8, s);
+    return true;
+}
+
+}  // namespace tmat

@@ -276,6 +276,24 @@ int unet_down_dev(Ctx *c, const float *X, int n, float *dout, hipStream_t s)
     for (size_t bi = 0; bi < c->down.size(); bi++) {
         auto &d = c->down[bi];
         // prev = b0 (n, H, H, cin)
+        if (c->fused_sep && c->sep_ws && sepconv_ws_supported(H, H, d.cin, d.cout) && sepconv_ws_supported(H, H, d.cout, d.cout) &&
+            ((d.cout / 4) & (d.cout / 4 - 1)) == 0) {
+            // wave-specialised fused kernels (sepconv_ws_kernels.hip): depthwise producers + MFMA consumers in one workgroup
+            if (!launch_sepconv_ws(b0, n, H, H, d.cin, bi > 0, d.dw[0], d.pw[0], d.cout, d.scale[0], d.shift[0], 1, b2, s)) return TMAT_E_ARG;
+            ConvArgs r{};
+            r.in = b0; r.N = n; r.h = H; r.w = H; r.Cin = d.cin; r.ksize = 1; r.stride = 2; r.W = d.res_w; r.Cout = d.cout;
+            r.scale = nullptr; r.shift = d.res_b; r.out = b1;
+            if (!conv(c, r, s)) return TMAT_E_ARG;
+            float *nxt = bi + 1 == c->down.size() ? dout : b0;
+            if (c->fused_pool) {
+                if (!launch_sepconv_pool_ws(b2, n, H, H, d.cout, 0, d.dw[1], d.pw[1], d.cout, d.scale[1], d.shift[1], 0, b3, b1, nxt, s)) return TMAT_E_ARG;
+            } else {
+                if (!launch_sepconv_ws(b2, n, H, H, d.cout, 0, d.dw[1], d.pw[1], d.cout, d.scale[1], d.shift[1], 0, b3, s)) return TMAT_E_ARG;
+                launch_maxpool_add(b3, n, H, H, d.cout, b1, nxt, s);
+            }
+            H /= 2;
+            continue;
+        }
         if (c->fused_sep && d.dwq[0] && d.dwq[1] && sepconv_supported(H, H, d.cin, d.cout) && sepconv_supported(H, H, d.cout, d.cout)) {
             // stem output is already >= 0, so ReLU on load is the identity in the first block
             if (!launch_sepconv(b0, n, H, H, d.cin, bi > 0, d.dwq[0], d.pwT[0], d.cout, d.scale[0], d.shift[0], 1, b2, s)) return TMAT_E_ARG;
@@ -460,6 +478,7 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
     c->max_patches = max_patches > 0 ? max_patches : 400;
     if (const char *e = getenv("TMAT_FUSED_SEP")) c->fused_sep = atoi(e) != 0;
     if (const char *e = getenv("TMAT_FUSED_POOL")) c->fused_pool = atoi(e) != 0;
+    if (const char *e = getenv("TMAT_SEP_WS")) c->sep_ws = atoi(e) != 0;
     if (const char *e = getenv("TMAT_DMT_DEVICE")) c->dmt_device = atoi(e) != 0;
     if (const char *e = getenv("TMAT_THIN_DEVICE")) c->thin_device = atoi(e) != 0;
     // the UNet stream gets the highest priority, the side stream of the post-processing stages (thinning rounds, finish,

@@ -140,6 +140,7 @@ struct Ctx {
     uint32_t *ma_table = nullptr;                            // its 512-entry decision table, 16 words
     bool dmt_device = true;                                  // DMT key build + lower-star sort on the device (TMAT_DMT_DEVICE=0: host)
     bool fused_pool = true;                                  // max-pool + residual add fused behind the second separable convolution (TMAT_FUSED_POOL=0: separate kernel)
+    bool sep_ws = true;                                      // wave-specialised form of the fused separable kernel (TMAT_SEP_WS=0: sepconv_mfma_kernel)
     bool fused_sep = true;                                   // fused depthwise->pointwise kernel where the level allows (TMAT_FUSED_SEP=0: off)
     // profiling of the dominant kernel family
     bool prof_on = false;
