@@ -293,8 +293,10 @@ int tmat_dev_free(tmat_handle h, void *dev_ptr);
 int tmat_dev_upload(tmat_handle h, void *dev_dst, const void *host_src, size_t bytes);
 
 /*
- * Host pixel stages, exposed one by one for stage-wise parity tests (csrc/postproc.cpp).  They are
- * the implementation the batch entry points above use for these stages -- not a fallback.
+ * Host pixel stages, exposed one by one for stage-wise parity tests (csrc/postproc.cpp): host twins of the device
+ * stages.  The batch entry points above run these stages on the GPU (morph_kernels.hip, thin_kernels.hip,
+ * finish_kernels.hip); the twins are reached only through these test entry points, TMAT_THIN_DEVICE=0 and images with
+ * h^2 + w^2 >= 2^27 -- they are not a fallback for a missing device.
  *   lanczos4: cv2.resize(INTER_LANCZOS4) on u16 (compute_branches.py:312); rescale01: rescale_intensity
  *   (0,1) of an integer image -> f32 (:316); rescale255: rescale_intensity (0,255) in f32 (:419);
  *   filter_mask: transforms.filter_branch_seg_mask (transforms.py:306-361); skeletonize: skimage
@@ -333,6 +335,22 @@ int tmat_gather_rows(void *rccl_comm, const tmat_row *rows_dev, int n_local, tma
 enum { TMAT_ZPROJ_FS = 0, TMAT_ZPROJ_MIN = 1, TMAT_ZPROJ_MAX = 2, TMAT_ZPROJ_AVG = 3, TMAT_ZPROJ_MED = 4 };
 int tmat_zproj_batch(tmat_handle h, const uint16_t *stacks, int n, int Z, int H, int W, int method, void *out);
 int tmat_zproj_dev(tmat_handle h, const uint16_t *stacks_dev, int n, int Z, int H, int W, int method, void *out_dev);
+
+/*
+ * Arithmetic of the dense convolutions of the UNet (reference: keras Model.predict in float32, models.py:615-622, 644).
+ *   TMAT_PRECISION_F32    (default) f32 operands on v_mfma_f32_32x32x2_f32: bit-exact with oracle/unet_exact.c.
+ *   TMAT_PRECISION_BF16X3 opt-in split precision: every f32 operand as a bf16 hi + bf16 lo pair, three bf16 MFMAs per
+ *                         product (lo*hi + hi*lo + hi*hi) with f32 accumulation; about 2^-16 relative error per product,
+ *                         NOT bit-exact; gated by the north-star tolerance (branch counts equal, lengths within 1e-4) in
+ *                         tests/test_gpu_alt_precision.py and reported by bench.py as a separate "alt" block.  Applies to the
+ *                         3x3 / sub-pixel / 1x1 convolutions of conv_mfma_kernel; the fused separable convolutions, stem and
+ *                         final layer stay f32.
+ * Takes effect for the calls that follow (the handle's streams are drained first).  The environment variable
+ * TMAT_PRECISION=f32|bf16x3 selects the mode at tmat_create.
+ */
+#define TMAT_PRECISION_F32 0
+#define TMAT_PRECISION_BF16X3 1
+int tmat_set_precision(tmat_handle h, int mode);
 
 /*
  * Timing hook for bench.py's roofline line: accumulated HIP-event time (ms) and launch count of

@@ -65,6 +65,50 @@ static bool upload(Ctx *c, const std::vector<float> &v, float **dev)
     c->owned.push_back(*dev);
     return hip_ok(hipMemcpy(*dev, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice), "hipMemcpy(weights)");
 }
+// weights of an MFMA convolution ([taps][Cout][Cin], k contiguous): the host copy is kept so that tmat_set_precision can
+// make the split-precision copy later
+static bool upload_conv(Ctx *c, const std::vector<float> &v, int cin, float **dev)
+{
+    if (!upload(c, v, dev)) return false;
+    c->conv_w_host[*dev] = ConvWHost{v, cin};
+    return true;
+}
+
+// round-to-nearest-even f32 -> bf16 (finite inputs: weights)
+static uint16_t bf16_rne(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float bf16_to_f32(uint16_t b)
+{
+    const uint32_t u = (uint32_t)b << 16;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
+// Split-precision copy of conv weights for conv_mfma_kernel<..., PREC = 1> (unet_kernels.hip): rows of Cin f32 values become
+// rows of the same byte length in which every 128-byte block of 32 input channels holds 32 bf16 hi = rne(w) followed by 32
+// bf16 lo = rne(w - hi).
+static std::vector<float> split_bf16(const std::vector<float> &w, int cin)
+{
+    std::vector<float> out(w.size());
+    uint16_t *o = reinterpret_cast<uint16_t *>(out.data());
+    const size_t rows = w.size() / cin;
+    for (size_t r = 0; r < rows; r++)
+        for (int cb = 0; cb < cin / 32; cb++) {
+            const float *src = &w[r * cin + cb * 32];
+            uint16_t *dst = o + (r * cin + cb * 32) * 2;
+            for (int k = 0; k < 32; k++) {
+                const uint16_t hi = bf16_rne(src[k]);
+                dst[k] = hi;
+                dst[32 + k] = bf16_rne(src[k] - bf16_to_f32(hi));
+            }
+        }
+    return out;
+}
 
 // scale = f32(gamma / sqrt(var + eps)); shift = f32(beta + (bias - mean) * scale_f64)   (BN folding)
 static void fold_bn(const Tensor &bn, const Tensor &bias, std::vector<float> &scale, std::vector<float> &shift)
@@ -178,13 +222,13 @@ static bool build_model(Ctx *c, const std::map<std::string, Tensor> &m)
                 }
             }
             if (!upload(c, std::vector<float>(dw.data, dw.data + dw.count), &d.dw[s]) ||
-                !upload(c, k_contiguous(pw.data, 1, pw.shape[0], pw.shape[1]), &d.pw[s]) || !upload(c, sc, &d.scale[s]) ||
+                !upload_conv(c, k_contiguous(pw.data, 1, pw.shape[0], pw.shape[1]), pw.shape[0], &d.pw[s]) || !upload(c, sc, &d.scale[s]) ||
                 !upload(c, sh, &d.shift[s])) return false;
             d.cout = pw.shape[1];
         }
         if (!need(m, p + ".res.w", w) || !need(m, p + ".res.b", rb)) return false;
         if (w.count != (size_t)d.cin * d.cout || (int)rb.count != d.cout) { set_error("weights: residual convolution of " + p + " has unexpected shape"); return false; }
-        if (!upload(c, k_contiguous(w.data, 1, d.cin, d.cout), &d.res_w) ||
+        if (!upload_conv(c, k_contiguous(w.data, 1, d.cin, d.cout), d.cin, &d.res_w) ||
             !upload(c, std::vector<float>(rb.data, rb.data + rb.count), &d.res_b)) return false;
         c->down.push_back(d);
         cin = d.cout;
@@ -202,14 +246,14 @@ static bool build_model(Ctx *c, const std::map<std::string, Tensor> &m)
             fold_bn(bn, b, sc, sh);
             const std::vector<float> w9 = convt_as_conv(w);
             const int I = w.shape[3], O = w.shape[2];
-            if (!upload(c, k_contiguous(w9.data(), 9, I, O), &u.ct[s]) || !upload(c, sc, &u.scale[s]) || !upload(c, sh, &u.shift[s])) return false;
+            if (!upload_conv(c, k_contiguous(w9.data(), 9, I, O), I, &u.ct[s]) || !upload(c, sc, &u.scale[s]) || !upload(c, sh, &u.shift[s])) return false;
             // blocks after the first read a 2x nearest-upsampled tensor in their first convolution: sub-pixel form
-            if (s == 0 && j > 0 && !upload(c, k_contiguous(subpixel_weights(w9, I, O).data(), 16, I, O), &u.ct_sub)) return false;
+            if (s == 0 && j > 0 && !upload_conv(c, k_contiguous(subpixel_weights(w9, I, O).data(), 16, I, O), I, &u.ct_sub)) return false;
             u.cout = w.shape[2];
         }
         if (!need(m, p + ".res.w", w) || !need(m, p + ".res.b", rb)) return false;
         if (w.count != (size_t)u.cin * u.cout || (int)rb.count != u.cout) { set_error("weights: residual convolution of " + p + " has unexpected shape"); return false; }
-        if (!upload(c, k_contiguous(w.data, 1, u.cin, u.cout), &u.res_w) ||
+        if (!upload_conv(c, k_contiguous(w.data, 1, u.cin, u.cout), u.cin, &u.res_w) ||
             !upload(c, std::vector<float>(rb.data, rb.data + rb.count), &u.res_b)) return false;
         c->up.push_back(u);
         cin = u.cout;
@@ -258,6 +302,10 @@ static bool conv(Ctx *c, ConvArgs a, hipStream_t st)
     if (dom) {
         double H = (double)a.h, W = (double)a.w;
         prof_begin(c, 2.0 * a.N * H * W * 9.0 * a.Cin * a.Cout, st);
+    }
+    if (c->precision == 1) {        // opt-in split precision: the same launch on the split copy of the weights
+        auto it = c->wsplit.find(a.W);
+        if (it != c->wsplit.end()) { a.W = it->second; a.prec = 1; }
     }
     bool ok = launch_conv(a, st);
     if (dom) prof_end(c, st);
@@ -479,6 +527,12 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
     if (const char *e = getenv("TMAT_FUSED_SEP")) c->fused_sep = atoi(e) != 0;
     if (const char *e = getenv("TMAT_FUSED_POOL")) c->fused_pool = atoi(e) != 0;
     if (const char *e = getenv("TMAT_SEP_WS")) c->sep_ws = atoi(e) != 0;
+    const char *prec_env = getenv("TMAT_PRECISION");
+    if (prec_env && strcmp(prec_env, "f32") && strcmp(prec_env, "bf16x3")) {
+        set_error("tmat_create: TMAT_PRECISION must be f32 or bf16x3");
+        delete c;
+        return TMAT_E_ARG;
+    }
     if (const char *e = getenv("TMAT_DMT_DEVICE")) c->dmt_device = atoi(e) != 0;
     if (const char *e = getenv("TMAT_THIN_DEVICE")) c->thin_device = atoi(e) != 0;
     // the UNet stream gets the highest priority, the side stream of the post-processing stages (thinning rounds, finish,
@@ -544,6 +598,10 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
         c->win_host = wind;
     }
     *out = (tmat_handle)c;
+    if (prec_env && !strcmp(prec_env, "bf16x3")) {
+        const int rc = tmat_set_precision((tmat_handle)c, TMAT_PRECISION_BF16X3);
+        if (rc) { tmat_destroy((tmat_handle)c); *out = nullptr; return rc; }
+    }
     return TMAT_OK;
 }
 
@@ -653,6 +711,27 @@ int tmat_set_input_depth(tmat_handle h, int bits)
     Ctx *c = (Ctx *)h;
     if (!c || (bits != 8 && bits != 16)) { set_error("tmat_set_input_depth: bits must be 8 or 16"); return TMAT_E_ARG; }
     c->input_sat = bits == 8 ? 255.f : 65535.f;
+    return TMAT_OK;
+}
+
+int tmat_set_precision(tmat_handle h, int mode)
+{
+    Ctx *c = (Ctx *)h;
+    if (!c || !has_model(c) || (mode != TMAT_PRECISION_F32 && mode != TMAT_PRECISION_BF16X3)) {
+        set_error("tmat_set_precision: needs a model handle and mode TMAT_PRECISION_F32 or TMAT_PRECISION_BF16X3");
+        return TMAT_E_ARG;
+    }
+    TMAT_HIP(hipSetDevice(c->device));
+    if (mode == TMAT_PRECISION_BF16X3) {
+        for (auto &kv : c->conv_w_host) {
+            if (c->wsplit.count(kv.first)) continue;
+            float *dev = nullptr;
+            if (!upload(c, split_bf16(kv.second.w, kv.second.cin), &dev)) return TMAT_E_HIP;
+            c->wsplit[kv.first] = dev;
+        }
+    }
+    TMAT_HIP(hipStreamSynchronize(c->stream));
+    c->precision = mode;
     return TMAT_OK;
 }
 

@@ -24,6 +24,7 @@ struct UpBlock {
     float *res_w = nullptr, *res_b = nullptr;
 };
 struct ProfEv { hipEvent_t e0, e1; double flops; };
+struct ConvWHost { std::vector<float> w; int cin; };        // host copy of an MFMA convolution's weights ([rows][cin])
 
 // per-geometry buffers of the batch pipeline (pipeline.cpp)
 struct PassBuf {
@@ -140,6 +141,9 @@ struct Ctx {
     uint32_t *ma_table = nullptr;                            // its 512-entry decision table, 16 words
     bool dmt_device = true;                                  // DMT key build + lower-star sort on the device (TMAT_DMT_DEVICE=0: host)
     bool fused_pool = true;                                  // max-pool + residual add fused behind the second separable convolution (TMAT_FUSED_POOL=0: separate kernel)
+    int precision = 0;                                       // TMAT_PRECISION_F32 (bit-exact contract) or TMAT_PRECISION_BF16X3 (opt-in, tmat_set_precision)
+    std::map<const float *, ConvWHost> conv_w_host;          // device pointer of every MFMA convolution weight tensor -> its host copy
+    std::map<const float *, float *> wsplit;                 // ... -> its split-precision copy on the device (made on first use)
     bool sep_ws = true;                                      // wave-specialised form of the fused separable kernel (TMAT_SEP_WS=0: sepconv_mfma_kernel)
     bool fused_sep = true;                                   // fused depthwise->pointwise kernel where the level allows (TMAT_FUSED_SEP=0: off)
     // profiling of the dominant kernel family

@@ -26,6 +26,7 @@ struct ConvArgs {
     int rs;
     int relu_out;
     float *out;           // (N, h/stride, w/stride, Cout); ksize 2: (N, 2h, 2w, Cout)
+    int prec;             // 0: f32 MFMA (bit-exact contract); 1: bf16x3 split precision, W then points to the split copy of the weights
 };
 // returns false (and sets the error) on unsupported shapes
 bool launch_conv(const ConvArgs &a, hipStream_t s);

@@ -77,6 +77,7 @@ def lib():
     L.tmat_resnet_predict.argtypes = [vp, i, vp, i, i, vp]
     L.tmat_inv_depth_predict.argtypes = [vp, vp, i, vp, i, i, i, i, vp, vp]
     L.tmat_prof_enable.argtypes = [vp, i]
+    L.tmat_set_precision.argtypes = [vp, i]
     L.tmat_prof_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), i]
     for name in EXPORTS:
         fn = getattr(L, name)
@@ -91,7 +92,7 @@ EXPORTS = [
     "tmat_predict_smooth", "tmat_segment_batch", "tmat_postprocess_batch", "tmat_filter_edt_batch", "tmat_medial_axis_batch", "tmat_finish_batch", "tmat_filter_mask_batch", "tmat_zproj_batch", "tmat_zproj_dev", "tmat_gather_rows",
     "tmat_dmt_graph", "tmat_morse_stats",
     "tmat_analyze_batch_dev", "tmat_analyze_batch", "tmat_dev_alloc", "tmat_dev_free", "tmat_dev_upload",
-    "tmat_prof_enable", "tmat_prof_read", "tmat_host_lanczos4_u16", "tmat_host_rescale01_u16",
+    "tmat_prof_enable", "tmat_prof_read", "tmat_set_precision", "tmat_host_lanczos4_u16", "tmat_host_rescale01_u16",
     "tmat_host_rescale255_f32", "tmat_host_filter_mask", "tmat_host_skeletonize", "tmat_host_medial_axis",
     "tmat_host_permutation", "tmat_host_postprocess",
     "tmat_set_gaussian_table", "tmat_host_gaussian_kernel1d", "tmat_gaussian_f32", "tmat_sato_batch", "tmat_stack_prepare", "tmat_vessel_field",
@@ -212,6 +213,14 @@ class Handle:
         out = np.empty((n, H, W), np.float64 if m >= 3 else np.uint16)
         check(lib().tmat_zproj_batch(self._h, ptr(a), n, Z, H, W, m, ptr(out)), "tmat_zproj_batch")
         return out.astype(stacks.dtype) if m < 3 else out
+
+    def set_precision(self, mode="f32"):
+        """arithmetic of the UNet's dense convolutions: "f32" (bit-exact contract, default) or "bf16x3" (opt-in split
+        precision on the bf16 matrix cores, include/tmat.h:tmat_set_precision)"""
+        modes = {"f32": 0, "bf16x3": 1}
+        if mode not in modes:
+            raise ValueError(f"precision must be one of {sorted(modes)}")
+        check(lib().tmat_set_precision(self._h, modes[mode]), "tmat_set_precision")
 
     def prof_enable(self, on=True):
         check(lib().tmat_prof_enable(self._h, int(on)), "tmat_prof_enable")
