@@ -100,6 +100,29 @@ int tmat_postprocess_batch(tmat_handle h, const double *pred, int n, int hh, int
 int tmat_filter_edt_batch(tmat_handle h, const double *pred, int n, int hh, int ww, uint8_t *filtered, double *dist);
 
 /*
+ * The two pixel stages in front of the UNet on their own (compute_branches.py:309-316): cv2.resize(img, round(shape *
+ * ds_ratio), INTER_LANCZOS4) and rescale_intensity(out_range=(0, 1)).astype(float32), on the device.  imgs (n, H, W) u16
+ * host; x (n, round(W ds_ratio), round(H ds_ratio)) f32 host.  This is the image `make_well_mask` sees when --detect-well
+ * is given (:318-319); tmat_predict_smooth continues from it.
+ */
+int tmat_preprocess_batch(tmat_handle h, const uint16_t *imgs, int n, int H, int W, double ds_ratio, float *x);
+
+/*
+ * Well detection (--detect-well), device stages of fl_tissue_model_tools/well_mask_generation.py:
+ *   tmat_well_threshold = auto_threshold_well (:236-277): skimage gaussian(sigma 1) -> rescale_intensity(0..255) -> uint8 ->
+ *     corner medians decide whether to invert -> skimage.filters.threshold_otsu (256-bin histogram kernel + a decision
+ *     kernel that evaluates the inter-class variance exactly as numpy does) -> binary_erosion(footprint=disk(5)).
+ *     img (H, W) f32 host -> out (H, W) u8 host.  H, W >= 20.
+ *   tmat_canny_mask = skimage.feature.canny(mask, sigma) of a boolean image, default thresholds (:165, :201): mask, edges
+ *     (H, W) u8 host.
+ * The small host steps between them (nearest-neighbour rescale to <= 200 px, scipy.spatial.ConvexHull, the hull mask, the
+ * seeded random superellipse search :16-91) are Python host code in tmat_amd/well_mask_generation.py.
+ * A handle from tmat_create_plain is enough.
+ */
+int tmat_well_threshold(tmat_handle h, const float *img, int H, int W, uint8_t *out);
+int tmat_canny_mask(tmat_handle h, const uint8_t *mask, int H, int W, double sigma, uint8_t *edges);
+
+/*
  * transforms.filter_branch_seg_mask(mask, footprint, remove_isolated) (transforms.py:306-361) on the GPU for a batch of
  * uint8 masks: use_median 1 = footprint disk(2) (the default), 0 = footprint None (compute_branches.py:293).
  * mask, filtered (n, h, w) u8.  A handle from tmat_create_plain is enough.
@@ -348,6 +371,14 @@ int tmat_zproj_dev(tmat_handle h, const uint16_t *stacks_dev, int n, int Z, int 
  * Takes effect for the calls that follow (the handle's streams are drained first).  The environment variable
  * TMAT_PRECISION=f32|bf16x3 selects the mode at tmat_create.
  */
+/*
+ * UNetXceptionPatchSegmentor's optional input normalisation, x = (x - norm_mean) / norm_std in float32 (reference
+ * models.py:600-612, 636-637; keys norm_mean / norm_std of the model config), applied on the device in front of
+ * predict_img_with_smooth_windowing by every entry point that runs it (tmat_predict_smooth, tmat_segment_batch,
+ * tmat_analyze_batch*).  Off by default (the shipped unet_patch_segmentor_1.json has no such keys).
+ */
+int tmat_set_input_norm(tmat_handle h, int on, double norm_mean, double norm_std);
+
 #define TMAT_PRECISION_F32 0
 #define TMAT_PRECISION_BF16X3 1
 int tmat_set_precision(tmat_handle h, int mode);

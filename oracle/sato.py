@@ -126,6 +126,12 @@ def unsharp_mask(vol: np.ndarray, radius=2, amount=2) -> np.ndarray:
 def canny0(image: np.ndarray) -> np.ndarray:
     """skimage.feature.canny(image, sigma=0) with the default thresholds 0.1 / 0.2 (feature/_canny.py)"""
     sm = image.astype(image.dtype if image.dtype in (np.float32, np.float64) else np.float64) / (np.ones(image.shape) + np.finfo(float).eps)
+    return canny_from_smoothed(sm)
+
+
+def canny_from_smoothed(sm: np.ndarray) -> np.ndarray:
+    """feature/_canny.py after the smoothing step: sobel, 4-sector non-maximum suppression, hysteresis (0.1 / 0.2)"""
+    image = sm
     js = ndi.sobel(sm, axis=1)
     is_ = ndi.sobel(sm, axis=0)
     ai, aj = np.abs(is_), np.abs(js)

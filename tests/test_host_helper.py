@@ -61,5 +61,41 @@ def test_load_image_contract(tmp_path):
         helper.load_image(str(tmp_path / "rgb.png"))
     g, _ = helper.load_image(str(tmp_path / "rgb.png"), C=1)
     assert g.shape == (3, 4) and np.all(g == 7)
-    with pytest.raises(ValueError, match="time-series"):
+    with pytest.raises(ValueError, match="Time 1 is out of range"):           # the reference's message (helper.py:62-66)
         helper.load_image(str(tmp_path / "s0.tif"), T=1)
+
+
+def _save_pages(path, pages, description):
+    from PIL import TiffImagePlugin
+    ifd = TiffImagePlugin.ImageFileDirectory_v2()
+    ifd[270] = description
+    Image.fromarray(pages[0]).save(path, save_all=True, append_images=[Image.fromarray(p) for p in pages[1:]], tiffinfo=ifd)
+
+
+def test_time_series_and_channel_selection(tmp_path):
+    """--time N / --channel N (reference helper.load_image :57-84: get_image_data("ZYX", T=T, C=C)): the page of (t, z, c) follows
+    the OME DimensionOrder or ImageJ's channel-fastest hyperstack order"""
+    T, Z, Cn = 2, 3, 2
+    val = lambda t, z, c: np.full((4, 5), 100 * t + 10 * z + c, np.uint16)
+    # OME, DimensionOrder XYZCT: z fastest, then c, then t
+    pages = [val(t, z, c) for t in range(T) for c in range(Cn) for z in range(Z)]
+    ome = ('<OME><Image><Pixels DimensionOrder="XYZCT" SizeT="2" SizeZ="3" SizeC="2" SizeX="5" SizeY="4" PhysicalSizeX="0.5" '
+           'Type="uint16"></Pixels></Image></OME>')
+    _save_pages(tmp_path / "ome.tif", pages, ome)
+    st, sizes = helper.load_image(str(tmp_path / "ome.tif"), T=1, C=1)
+    assert st.shape == (Z, 4, 5) and [int(p[0, 0]) for p in st] == [101, 111, 121] and sizes.X == 0.5
+    with pytest.raises(ValueError, match="is a time series image but no time index was specified"):
+        helper.load_image(str(tmp_path / "ome.tif"), C=0)
+    with pytest.raises(ValueError, match="multi channel image but no color channel"):
+        helper.load_image(str(tmp_path / "ome.tif"), T=0)
+    with pytest.raises(ValueError, match="Color channel 2 is out of range"):
+        helper.load_image(str(tmp_path / "ome.tif"), T=0, C=2)
+    # ImageJ hyperstack: channels fastest, then slices, then frames; one slice per frame -> a 2-D image per (t, c)
+    pages = [val(t, 0, c) for t in range(3) for c in range(2)]
+    _save_pages(tmp_path / "ij.tif", pages, "ImageJ=1.53\nimages=6\nchannels=2\nframes=3\nhyperstack=true\n")
+    img, _ = helper.load_image(str(tmp_path / "ij.tif"), T=2, C=1)
+    assert img.shape == (4, 5) and int(img[0, 0]) == 201
+    # no layout metadata: pages are Z slices
+    _save_pages(tmp_path / "plainstack.tif", [val(0, z, 0) for z in range(4)], "nothing to see")
+    st, _ = helper.load_image(str(tmp_path / "plainstack.tif"))
+    assert st.shape == (4, 4, 5)

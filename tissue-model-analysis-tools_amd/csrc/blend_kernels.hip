@@ -67,6 +67,17 @@ __global__ __launch_bounds__(256) void minmax_f32_kernel(const float *__restrict
         mn[blockIdx.x] = lo; mx[blockIdx.x] = hi;
     }
 }
+// models.py:636-637: x = (x - norm_mean) / norm_std, float32 arithmetic (numpy: a Python float next to a float32 array)
+__global__ void norm_f32_kernel(float *__restrict__ x, size_t n, float mean, float sd)
+{
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) x[p] = (x[p] - mean) / sd;
+}
+void launch_norm_f32(float *x, size_t n, float mean, float sd, hipStream_t s)
+{
+    const size_t b = (n + 255) / 256;
+    hipLaunchKernelGGL(norm_f32_kernel, dim3((unsigned)(b < 8192 ? (b ? b : 1) : 8192)), dim3(256), 0, s, x, n, mean, sd);
+}
+
 void launch_minmax_f32(const float *x, int n, size_t per, float *mn, float *mx, hipStream_t s)
 {
     hipLaunchKernelGGL(minmax_f32_kernel, dim3(n), dim3(256), 0, s, x, per, mn, mx);

@@ -296,7 +296,7 @@ extern "C" int tmat_cell_area_batch(tmat_handle hd, const uint16_t *imgs, int n,
             if (!hip_ok(hipGetLastError(), "launch") || !hip_ok(hipMemcpyAsync(kh.data(), kept, n * 4, hipMemcpyDeviceToHost, s), "D2H") ||
                 !hip_ok(hipMemcpyAsync(ph.data(), dpar, (size_t)n * 11 * 8, hipMemcpyDeviceToHost, s), "D2H") ||
                 (thresholded && !hip_ok(hipMemcpyAsync(thresholded, dthr, nout, hipMemcpyDeviceToHost, s), "D2H")) ||
-                !hip_ok(hipStreamSynchronize(s), "sync")) fail(TMAT_E_HIP);
+                !hip_ok(hipStreamSynchronize(s), "sync")) { hipStreamSynchronize(s); fail(TMAT_E_HIP); }      // nothing may still be copying into kh / ph when they go out of scope
             else {
                 for (int i = 0; i < n; i++) area[i] = (double)kh[i] / (double)npx;          // compute_area_prop: np.sum(img > 0) / img.size
                 if (params) for (int i = 0; i < n; i++) for (int k = 0; k < 9; k++) params[(size_t)i * 9 + k] = ph[(size_t)i * 11 + k];

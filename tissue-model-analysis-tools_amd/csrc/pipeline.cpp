@@ -138,6 +138,7 @@ static int enqueue_front(Ctx *c, const uint16_t *imgs_dev, int k, int slot, cons
     hipStream_t s = (use_one_stream() || oversize) ? c->stream : c->stream2;
     launch_lanczos(imgs_dev, k, b.H, b.W, b.h, b.w, b.xi, b.xc, b.yi, b.yc, b.tmp, b.small, c->input_sat, s);
     launch_rescale01(b.small, k, (size_t)b.h * b.w, b.mn, b.mx, b.x, s);
+    if (c->norm_on) launch_norm_f32(b.x, (size_t)k * b.h * b.w, c->norm_mean, c->norm_std, s);      // models.py:636-637
     float *mn = (float *)c->scratch, *mx = mn + k;
     launch_minmax_f32(b.x, k, (size_t)b.h * b.w, mn, mx, s);
     launch_extract_tiles(b.x, mn, k, g, c->patch_in, s);
@@ -387,6 +388,34 @@ int tmat_segment_batch(tmat_handle hd, const uint16_t *imgs, int n, int H, int W
         if (rc) break;
         if (!hip_ok(hipStreamSynchronize(c->stream), "sync")) { rc = TMAT_E_HIP; break; }
         std::memcpy(pred + (size_t)i0 * h * w, c->pass.pred_host[0], (size_t)k * h * w * sizeof(double));
+    }
+    hipFree(dimg);
+    return rc;
+}
+
+int tmat_preprocess_batch(tmat_handle hd, const uint16_t *imgs, int n, int H, int W, double ds_ratio, float *x)
+{
+    Ctx *c = (Ctx *)hd;
+    if (c && !has_model(c)) { set_error("tmat_preprocess_batch: this handle has no model (tmat_create_plain)"); return TMAT_E_ARG; }
+    if (!c || !imgs || !x || n < 0 || H < 1 || W < 1) { set_error("tmat_preprocess_batch: bad argument"); return TMAT_E_ARG; }
+    if (n == 0) return TMAT_OK;
+    TMAT_HIP(hipSetDevice(c->device));
+    const int h = round_half_even((double)W * ds_ratio), w = round_half_even((double)H * ds_ratio);    // see analyze_dev
+    if (h < 1 || w < 1) { set_error("tmat_preprocess_batch: target shape is empty"); return TMAT_E_ARG; }
+    TileGeom g = make_geom(h, w, c->patch);
+    const int K = std::min(n, std::max(1, c->max_patches / g.tiles_per_img));
+    int rc = ensure_pass_buffers(c, K, H, W, h, w, std::max(1, c->pass.fh), std::max(1, c->pass.fw));
+    if (rc) return rc;
+    uint16_t *dimg = nullptr;
+    TMAT_HIP(hipMalloc((void **)&dimg, (size_t)K * H * W * sizeof(uint16_t)));
+    PassBuf &b = c->pass;
+    for (int i0 = 0; i0 < n && !rc; i0 += K) {
+        const int k = std::min(K, n - i0);
+        if (!hip_ok(hipMemcpyAsync(dimg, imgs + (size_t)i0 * H * W, (size_t)k * H * W * 2, hipMemcpyHostToDevice, c->stream), "H2D")) { rc = TMAT_E_HIP; break; }
+        launch_lanczos(dimg, k, b.H, b.W, b.h, b.w, b.xi, b.xc, b.yi, b.yc, b.tmp, b.small, c->input_sat, c->stream);
+        launch_rescale01(b.small, k, (size_t)b.h * b.w, b.mn, b.mx, b.x, c->stream);
+        if (!hip_ok(hipMemcpyAsync(x + (size_t)i0 * h * w, b.x, (size_t)k * h * w * sizeof(float), hipMemcpyDeviceToHost, c->stream), "D2H") ||
+            !hip_ok(hipStreamSynchronize(c->stream), "sync")) { hipStreamSynchronize(c->stream); rc = TMAT_E_HIP; break; }
     }
     hipFree(dimg);
     return rc;

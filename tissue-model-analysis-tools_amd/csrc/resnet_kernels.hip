@@ -350,7 +350,7 @@ int tmat_inv_depth_predict(tmat_handle hd, const int *model_ids, int n_models, c
             std::vector<float> ph((size_t)Z * n_models);
             if (!rc && (!hip_ok(hipMemcpyAsync(ph.data(), dp, ph.size() * 4, hipMemcpyDeviceToHost, s), "D2H") ||
                         (x_out && !hip_ok(hipMemcpyAsync(x_out, dx, (size_t)Z * npx * 3 * 4, hipMemcpyDeviceToHost, s), "D2H")) ||
-                        !hip_ok(hipStreamSynchronize(s), "sync"))) rc = TMAT_E_HIP;
+                        !hip_ok(hipStreamSynchronize(s), "sync"))) { hipStreamSynchronize(s); rc = TMAT_E_HIP; }      // drain before ph goes out of scope
             if (!rc) for (int z = 0; z < Z; z++) for (int mi = 0; mi < n_models; mi++) probs[(size_t)z * n_models + mi] = ph[(size_t)mi * Z + z];     // (Z, n_models)
         }
     }

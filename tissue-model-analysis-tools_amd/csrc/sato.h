@@ -26,6 +26,7 @@ struct CannyWs {
     const double *w_diff, *w_smooth;        // device tables [-1, 0, 1] and [1, 2, 1]
 };
 int canny0_dev(const float *img, int H, int W, const CannyWs &ws, uint8_t *edges, hipStream_t s);
+int canny_core_dev(int H, int W, const CannyWs &ws, uint8_t *edges, hipStream_t s);      // ws.sm holds the smoothed image
 int ecc_diam_select_dev(const uint8_t *mask, int H, int W, double thresh, int *L, unsigned long long *mom, uint8_t *out, double *val_out, hipStream_t s);
 void launch_where(const uint8_t *m, const float *a, const float *b, size_t n, float *out, hipStream_t s);     // b null: zeros
 void launch_grow(const uint8_t *m, const float *v, int H, int W, uint8_t *out, hipStream_t s);

@@ -420,6 +420,13 @@ int canny0_dev(const float *img, int H, int W, const CannyWs &ws, uint8_t *edges
 {
     const size_t n = (size_t)H * W;
     hipLaunchKernelGGL(canny_norm_kernel, grid_for(n), dim3(256), 0, s, img, n, ws.sm);
+    return canny_core_dev(H, W, ws, edges, s);
+}
+
+// feature/_canny.py after the smoothing step, from the smoothed image in ws.sm (f64)
+int canny_core_dev(int H, int W, const CannyWs &ws, uint8_t *edges, hipStream_t s)
+{
+    const size_t n = (size_t)H * W;
     // ndi.sobel(axis): correlate1d [-1, 0, 1] along the axis, then [1, 2, 1] along the other; 'reflect'
     launch_corr1d_f64(ws.sm, ws.t0, (size_t)H, W, 1, ws.w_diff, 1, -1, EXT_REFLECT, s);       // jsobel: axis 1
     launch_corr1d_f64(ws.t0, ws.js, 1, H, W, ws.w_smooth, 1, 1, EXT_REFLECT, s);

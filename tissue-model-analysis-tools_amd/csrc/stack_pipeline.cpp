@@ -8,6 +8,7 @@
 #include "postproc.h"
 #include "morph.h"
 #include "sato.h"
+#include "wellmask.h"
 
 #include <algorithm>
 #include <cmath>
@@ -32,7 +33,12 @@ struct Arena {
         ptrs.push_back(p);
         return (T *)p;
     }
-    ~Arena() { for (void *p : ptrs) hipFree(p); }
+    hipStream_t drain = nullptr;            // synchronised before anything is freed: an early error return must not leave async work behind
+    ~Arena()
+    {
+        if (drain) hipStreamSynchronize(drain);
+        for (void *p : ptrs) hipFree(p);
+    }
 };
 
 // device copy of a gaussian table, made on first use (synchronous copy: a few hundred doubles)
@@ -113,6 +119,7 @@ int vessel_field_dev(Ctx *c, const float *vol, int Z, int h, int w, int form, fl
     const int D = Z - 1;
     const size_t npx = (size_t)h * w, nv = (size_t)D * npx;
     Arena A;
+    A.drain = s;
     float *x = A.get<float>(nv), *vess = A.get<float>(nv), *bufs[7];
     for (float *&b : bufs) b = A.get<float>(nv);
     float *vessels = A.get<float>(npx), *vcur = A.get<float>(npx), *vblur = A.get<float>(npx), *vtmp = A.get<float>(npx);
@@ -194,6 +201,7 @@ int stack_prepare_dev(Ctx *c, uint16_t *stack, int Z, int H, int W, int oh, int 
 {
     const size_t nin = (size_t)Z * H * W, nout = (size_t)Z * oh * ow;
     Arena A;
+    A.drain = s;
     double *fa = A.get<double>(nin), *fb = A.get<double>(nin), *zoomed = A.get<double>(nout), *lohi = A.get<double>(4);
     unsigned long long *mm = A.get<unsigned long long>(2);
     std::vector<int> r0, r1, c0, c1;
@@ -263,6 +271,7 @@ int tmat_gaussian_f32(tmat_handle hd, const float *x, int d0, int d1, int d2, do
     const size_t n = (size_t)d0 * d1 * d2;
     hipStream_t s = c->stream;
     Arena A;
+    A.drain = s;
     float *a = A.get<float>(n), *b = A.get<float>(n);
     if (!A.ok) return TMAT_E_HIP;
     TMAT_HIP(hipMemcpyAsync(a, x, n * 4, hipMemcpyHostToDevice, s));
@@ -273,6 +282,81 @@ int tmat_gaussian_f32(tmat_handle hd, const float *x, int d0, int d1, int d2, do
     std::swap(src, dst);
     if (!gauss_pass_f32(c, src, dst, Pass{sigma, 0, d2, 1, (size_t)d0 * d1}, 4.0, mode, s)) return TMAT_E_HIP;
     TMAT_HIP(hipMemcpyAsync(out, dst, n * 4, hipMemcpyDeviceToHost, s));
+    TMAT_HIP(hipStreamSynchronize(s));
+    return TMAT_OK;
+}
+
+/* well_mask_generation.auto_threshold_well (reference :236-277) on the device: img (H, W) f32 -> thresholded, eroded mask u8 */
+int tmat_well_threshold(tmat_handle hd, const float *img, int H, int W, uint8_t *out)
+{
+    Ctx *c = (Ctx *)hd;
+    if (!c || !img || !out || H < 20 || W < 20 || (long long)H * W > (1LL << 30)) { set_error("tmat_well_threshold: bad argument (images of at least 20 x 20)"); return TMAT_E_ARG; }
+    TMAT_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const size_t n = (size_t)H * W;
+    Arena A;
+    A.drain = s;
+    float *a = A.get<float>(n), *b = A.get<float>(n), *mm = A.get<float>(2);
+    uint8_t *u8 = A.get<uint8_t>(n), *th = A.get<uint8_t>(n), *er = A.get<uint8_t>(n);
+    unsigned *hist = A.get<unsigned>(5 * 256);
+    int *decision = A.get<int>(2), *offs = A.get<int>(2 * 81);
+    if (!A.ok) return TMAT_E_HIP;
+    int o[2 * 81], k = 0;
+    for (int dy = -5; dy <= 5; dy++) for (int dx = -5; dx <= 5; dx++) if (dy * dy + dx * dx <= 25) { o[2 * k] = dy; o[2 * k + 1] = dx; k++; }     // disk(5): 81
+    TMAT_HIP(hipMemcpyAsync(offs, o, sizeof(int) * 2 * k, hipMemcpyHostToDevice, s));
+    TMAT_HIP(hipMemcpyAsync(a, img, n * 4, hipMemcpyHostToDevice, s));
+    // gaussian(image, sigma=1): ndi.gaussian_filter, mode 'nearest', truncate 4, float32 after each axis
+    if (!gauss_pass_f32(c, a, b, Pass{1.0, 0, H, W, 1}, 4.0, EXT_NEAREST, s) || !gauss_pass_f32(c, b, a, Pass{1.0, 0, W, 1, (size_t)H}, 4.0, EXT_NEAREST, s))
+        return TMAT_E_HIP;
+    launch_minmax_f32(a, 1, n, mm, mm + 1, s);
+    launch_wm_rescale_u8(a, n, mm, mm + 1, u8, s);
+    launch_wm_hist(u8, H, W, hist, s);
+    launch_wm_decide(hist, H, W, decision, s);
+    launch_wm_threshold(u8, n, decision, th, s);
+    launch_wm_erode(th, H, W, offs, k, er, s);
+    TMAT_HIP(hipGetLastError());
+    TMAT_HIP(hipMemcpyAsync(out, er, n, hipMemcpyDeviceToHost, s));
+    TMAT_HIP(hipStreamSynchronize(s));
+    return TMAT_OK;
+}
+
+/* skimage.feature.canny(mask, sigma) of a boolean image with the default thresholds (reference calls:
+ * well_mask_generation.py:165, :201): mask (H, W) u8 -> edges u8 */
+int tmat_canny_mask(tmat_handle hd, const uint8_t *mask, int H, int W, double sigma, uint8_t *edges)
+{
+    Ctx *c = (Ctx *)hd;
+    if (!c || !mask || !edges || H < 3 || W < 3 || !(sigma > 0) || sigma > 16 || (long long)H * W > (1LL << 26)) { set_error("tmat_canny_mask: bad argument"); return TMAT_E_ARG; }
+    TMAT_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int r = gauss_radius(sigma, 4.0);
+    const int Hp = H + 2 * r, Wp = W + 2 * r;
+    const size_t npx = (size_t)H * W, npad = (size_t)Hp * Wp;
+    Arena A;
+    A.drain = s;
+    uint8_t *m = A.get<uint8_t>(npx), *e = A.get<uint8_t>(npx);
+    double *pa = A.get<double>(npad), *pb = A.get<double>(npad), *pt = A.get<double>(npad);
+    CannyWs cw{};
+    cw.sm = A.get<double>(npx); cw.t0 = A.get<double>(npx); cw.is_ = A.get<double>(npx); cw.js = A.get<double>(npx); cw.mag = A.get<double>(npx);
+    cw.low = A.get<uint8_t>(npx); cw.high = A.get<uint8_t>(npx); cw.L = A.get<int>(npx); cw.flag = A.get<int>(npx);
+    double *tabs = A.get<double>(6);
+    if (!A.ok) return TMAT_E_HIP;
+    const double t[6] = {-1.0, 0.0, 1.0, 1.0, 2.0, 1.0};
+    TMAT_HIP(hipMemcpyAsync(tabs, t, sizeof(t), hipMemcpyHostToDevice, s));
+    cw.w_diff = tabs; cw.w_smooth = tabs + 3;
+    TMAT_HIP(hipMemcpyAsync(m, mask, npx, hipMemcpyHostToDevice, s));
+    // gaussian(x, sigma, mode='constant') of the image and of the all-ones mask (0.18.3 smooth_with_function_and_mask): zero padding
+    // by the kernel radius makes the boundary mode irrelevant
+    launch_wm_pad(m, H, W, r, pa, pb, s);
+    const GaussTable &gt = gauss_table(c, sigma, 0, r);
+    const double *w = table_dev(c, gt);
+    if (!w) return TMAT_E_HIP;
+    launch_corr1d_f64(pa, pt, 1, Hp, Wp, w, gt.r, gt.sym, EXT_NEAREST, s);
+    launch_corr1d_f64(pt, pa, (size_t)Hp, Wp, 1, w, gt.r, gt.sym, EXT_NEAREST, s);
+    launch_corr1d_f64(pb, pt, 1, Hp, Wp, w, gt.r, gt.sym, EXT_NEAREST, s);
+    launch_corr1d_f64(pt, pb, (size_t)Hp, Wp, 1, w, gt.r, gt.sym, EXT_NEAREST, s);
+    launch_wm_crop_div(pa, pb, H, W, r, cw.sm, s);
+    if (canny_core_dev(H, W, cw, e, s)) { set_error("tmat_canny_mask: kernel launch failed"); return TMAT_E_HIP; }
+    TMAT_HIP(hipMemcpyAsync(edges, e, npx, hipMemcpyDeviceToHost, s));
     TMAT_HIP(hipStreamSynchronize(s));
     return TMAT_OK;
 }
@@ -288,6 +372,7 @@ int tmat_sato_batch(tmat_handle hd, const float *imgs, int n, int hh, int ww, co
     const size_t total = (size_t)n * hh * ww;
     hipStream_t s = c->stream;
     Arena A;
+    A.drain = s;
     float *raw = A.get<float>(total), *x = A.get<float>(total), *best = A.get<float>(total), *bufs[7];
     for (float *&b : bufs) b = A.get<float>(total);
     if (!A.ok) return TMAT_E_HIP;
@@ -306,6 +391,7 @@ int tmat_stack_prepare(tmat_handle hd, const uint16_t *stack, int Z, int H, int 
     TMAT_HIP(hipSetDevice(c->device));
     const size_t nin = (size_t)Z * H * W, nout = (size_t)Z * out_h * out_w;
     Arena A;
+    A.drain = c->stream;
     uint16_t *ds = A.get<uint16_t>(nin);
     float *dv = A.get<float>(nout);
     if (!A.ok) return TMAT_E_HIP;
@@ -327,6 +413,7 @@ int tmat_vessel_field(tmat_handle hd, const float *vol, int Z, int hh, int ww, i
     TMAT_HIP(hipSetDevice(c->device));
     const size_t nvol = (size_t)Z * hh * ww, npx = (size_t)hh * ww;
     Arena A;
+    A.drain = c->stream;
     float *dv = A.get<float>(nvol), *df = A.get<float>(npx);
     if (!A.ok) return TMAT_E_HIP;
     TMAT_HIP(hipMemcpyAsync(dv, vol, nvol * 4, hipMemcpyHostToDevice, c->stream));
@@ -343,6 +430,7 @@ static int field_stats_dev(Ctx *c, const float *field, int fh, int fw, float t1,
 {
     const size_t npx = (size_t)fh * fw, nE = dmt_edge_count(fh, fw);
     Arena A;
+    A.drain = s;
     float *f255 = A.get<float>(npx), *mnmx = A.get<float>(2);
     int32_t *ids = A.get<int32_t>(nE);
     int *m = A.get<int>(1);
@@ -376,6 +464,7 @@ int tmat_field_stats(tmat_handle hd, const float *field, int fh, int fw, float g
     if (!c || !field || !row || fh < 2 || fw < 2) { set_error("tmat_field_stats: bad argument"); return TMAT_E_ARG; }
     TMAT_HIP(hipSetDevice(c->device));
     Arena A;
+    A.drain = c->stream;
     float *df = A.get<float>((size_t)fh * fw);
     if (!A.ok) return TMAT_E_HIP;
     TMAT_HIP(hipMemcpyAsync(df, field, (size_t)fh * fw * 4, hipMemcpyHostToDevice, c->stream));
@@ -399,6 +488,7 @@ int tmat_analyze_stack(tmat_handle hd, const uint16_t *stack, int Z, int H, int 
     const size_t nin = (size_t)Z * H * W, npx = (size_t)fh * fw;
     hipStream_t s = c->stream;
     Arena A;
+    A.drain = s;
     uint16_t *ds = A.get<uint16_t>(nin);
     float *vol = A.get<float>((size_t)Z * npx), *field = A.get<float>(npx);
     if (!A.ok) return TMAT_E_HIP;

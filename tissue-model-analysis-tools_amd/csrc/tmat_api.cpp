@@ -449,8 +449,9 @@ int ensure_patch_io(Ctx *c, int n_patches)
 }
 
 // predict_img_with_smooth_windowing on device: x_dev (n, hh, ww) f32 -> pred_dev (n, hh, ww) f64
-int predict_smooth_dev(Ctx *c, const float *x_dev, int n, int hh, int ww, double *pred_dev)
+int predict_smooth_dev(Ctx *c, float *x_dev, int n, int hh, int ww, double *pred_dev)
 {
+    if (c->norm_on) launch_norm_f32(x_dev, (size_t)n * hh * ww, c->norm_mean, c->norm_std, c->stream);
     const int P = c->patch;
     TileGeom g = make_geom(hh, ww, P);
     const int per_pass = std::max(1, c->max_patches / g.tiles_per_img);
@@ -711,6 +712,16 @@ int tmat_set_input_depth(tmat_handle h, int bits)
     Ctx *c = (Ctx *)h;
     if (!c || (bits != 8 && bits != 16)) { set_error("tmat_set_input_depth: bits must be 8 or 16"); return TMAT_E_ARG; }
     c->input_sat = bits == 8 ? 255.f : 65535.f;
+    return TMAT_OK;
+}
+
+int tmat_set_input_norm(tmat_handle h, int on, double mean, double sd)
+{
+    Ctx *c = (Ctx *)h;
+    if (!c || (on && !(sd != 0.0))) { set_error("tmat_set_input_norm: bad argument (norm_std must not be 0)"); return TMAT_E_ARG; }
+    c->norm_on = on != 0;
+    c->norm_mean = (float)mean;
+    c->norm_std = (float)sd;
     return TMAT_OK;
 }
 

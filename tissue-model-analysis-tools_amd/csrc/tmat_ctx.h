@@ -141,6 +141,8 @@ struct Ctx {
     uint32_t *ma_table = nullptr;                            // its 512-entry decision table, 16 words
     bool dmt_device = true;                                  // DMT key build + lower-star sort on the device (TMAT_DMT_DEVICE=0: host)
     bool fused_pool = true;                                  // max-pool + residual add fused behind the second separable convolution (TMAT_FUSED_POOL=0: separate kernel)
+    bool norm_on = false;                                    // models.py:636-637 input normalisation in front of the smooth prediction (tmat_set_input_norm)
+    float norm_mean = 0.f, norm_std = 1.f;
     int precision = 0;                                       // TMAT_PRECISION_F32 (bit-exact contract) or TMAT_PRECISION_BF16X3 (opt-in, tmat_set_precision)
     std::map<const float *, ConvWHost> conv_w_host;          // device pointer of every MFMA convolution weight tensor -> its host copy
     std::map<const float *, float *> wsplit;                 // ... -> its split-precision copy on the device (made on first use)
@@ -158,7 +160,7 @@ int unet_forward_dev(Ctx *c, const float *X, int n, float *Y, hipStream_t s);
 int ensure_patch_io(Ctx *c, int n_patches);
 int unet_down_dev(Ctx *c, const float *X, int n, float *dout, hipStream_t s);
 int unet_up_dev(Ctx *c, const float *dout, int n, float *Y, hipStream_t s);
-int predict_smooth_dev(Ctx *c, const float *x_dev, int n, int hh, int ww, double *pred_dev);
+int predict_smooth_dev(Ctx *c, float *x_dev, int n, int hh, int ww, double *pred_dev);      // x_dev is normalised in place when tmat_set_input_norm is on
 
 // numpy's pairwise summation of a contiguous f64 vector (np.add.reduce / np.mean inner loop):
 // 8 interleaved partial sums on blocks <= 128, recursive halves (rounded down to a multiple of 8) above.

@@ -62,6 +62,7 @@ struct TileGeom {
 };
 TileGeom make_geom(int hh, int ww, int ws);
 void launch_minmax_f32(const float *x, int n, size_t per, float *mn, float *mx, hipStream_t s);
+void launch_norm_f32(float *x, size_t n, float mean, float sd, hipStream_t s);          // x = (x - mean) / sd in place
 void launch_extract_tiles(const float *x, const float *padval, int n, const TileGeom &g, float *patches, hipStream_t s);
 void launch_blend(const float *pred_patches, const double *win1d, int n, const TileGeom &g, double *out, hipStream_t s);
 

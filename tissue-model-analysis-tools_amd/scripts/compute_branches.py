@@ -11,7 +11,7 @@ branch (:224-306), both on the GPU.
 
 Differences (documented in INTEGRATION.md): images are analysed in batches on the GPU (one process
 per GPU under torch.distributed.run; rows are gathered over RCCL and rank 0 writes the CSV);
---detect-well is outside the accelerated path; the PNG image dumps are opt-in (--visualizations; the
+--detect-well takes an explicit --well-seed (the reference's random search is unseeded); the PNG image dumps are opt-in (--visualizations; the
 matplotlib barcode / tree plots are not reproduced); --sato-hessian picks the Hessian of skimage.filters.sato
 (gaussian_derivatives = scikit-image >= 0.20, what the reference's pinned 0.22.0 runs; gradient = <= 0.19);
 without --image-width-microns (or the config key) the width comes from OME / ImageJ TIFF metadata
@@ -45,6 +45,9 @@ def parse_branching_args(arg_defaults):
     p.add_argument("--channel", type=int, default=None)
     p.add_argument("--time", type=int, default=None)
     p.add_argument("-w", "--detect-well", action="store_true")
+    p.add_argument("--well-seed", type=int, default=0,
+                   help="seed of the random superellipse search of --detect-well (the reference draws from numpy's global, unseeded "
+                        "generator: well_mask_generation.py:35; a run here equals a reference run after numpy.random.seed(SEED))")
     p.add_argument("--image-width-microns", type=float, default=None)
     p.add_argument("--graph-thresh-1", nargs="+", type=float, default=None)
     p.add_argument("--graph-thresh-2", nargs="+", type=float, default=None)
@@ -85,31 +88,28 @@ def create_output_csv(output_file: Path):
 
 
 def load_image_2d(path: str, channel=None, time=None) -> np.ndarray:
-    """One 2-D plane of an image file (reference helper.load_image :23-95 returns ZYX / YX for the chosen T and C).
-    Time series are outside this path: a --time other than 0 is refused, as compute_zproj.py does."""
-    if time not in (None, 0):
-        raise ValueError(f"{path}: --time {time}: time series are not supported by the accelerated path (only T = 0)")
+    """One 2-D plane of an image file (reference helper.load_image :23-95 returns ZYX / YX for the chosen T and C; a time
+    series needs --time, a multi-channel file --channel, as there).  .npy arrays: (H, W), or (C, H, W) / (H, W, C) with C <= 4."""
+    from tmat_amd import helper
     if path.endswith(".npy"):
         a = np.load(path)
+        if time not in (None, 0):
+            raise ValueError(f"Time {time} is out of range for {path} with times: 0 - 0")
+        if a.ndim == 3:
+            cax = [ax for ax in (2, 0) if a.shape[ax] <= 4]
+            if not cax:
+                raise ValueError(f"{path}: cannot tell the channel axis of shape {a.shape}")
+            if channel is None:
+                if a.shape[cax[0]] != 1:
+                    raise ValueError(f"{path} is a multi channel image but no color channel index was specified.")
+                channel = 0
+            if not 0 <= channel < a.shape[cax[0]]:
+                raise ValueError(f"Color channel {channel} is out of range for {path} with color channels: 0 - {a.shape[cax[0]] - 1}")
+            a = np.take(a, channel, axis=cax[0])
     else:
-        from PIL import Image
-        with Image.open(path) as im:
-            if getattr(im, "n_frames", 1) > 1:
-                raise ValueError(f"{path}: multi-page file (Z stack); project it first with compute_zproj.py")
-            a = np.array(im)
-    if a.ndim == 3:
-        # interleaved (H, W, C) as PIL decodes RGB(A) files, or planar (C, H, W) arrays: the channel axis is the one of
-        # length <= 4; anything else is ambiguous and refused rather than guessed
-        cax = [ax for ax in (2, 0) if a.shape[ax] <= 4]
-        if not cax:
-            raise ValueError(f"{path}: cannot tell the channel axis of shape {a.shape}")
-        if channel is None:
-            if a.shape[cax[0]] != 1:
-                raise ValueError(f"{path}: {a.shape[cax[0]]} channels, pass --channel")
-            channel = 0
-        if not 0 <= channel < a.shape[cax[0]]:
-            raise ValueError(f"{path}: --channel {channel} out of range for shape {a.shape}")
-        a = np.take(a, channel, axis=cax[0])
+        a, _ = helper.load_image(path, time, channel)
+        if a.ndim == 3:
+            raise ValueError(f"{path}: multi-page file (Z stack); project it first with compute_zproj.py")
     if a.ndim != 2:
         raise ValueError(f"{path}: expected a single-channel 2-D image, got shape {a.shape}")
     if a.dtype not in (np.uint8, np.uint16):
@@ -282,9 +282,6 @@ def main(args=None):
     if not Path(model_cfg_path).is_file():
         print(f"{FAIL}Model config file {model_cfg_path} does not exist.", flush=True)
         sys.exit(1)
-    if getattr(args, "detect_well", False):
-        print(f"{FAIL} --detect-well is not available in the accelerated path (unseeded random search in the reference).", flush=True)
-        sys.exit(1)
     in_root, out_root = Path(args.in_root), Path(args.out_root)
     if not in_root.is_dir():
         print(f"{FAIL} Input directory {in_root} does not exist.", flush=True)
@@ -318,10 +315,10 @@ def main(args=None):
         run_stacks(args, config, paths, out_root, rank, ws, local_rank)
         return
     model = models.get_unet_patch_segmentor_from_cfg(model_cfg_path, device_id=local_rank)
-    if model.norm_mean is not None and model.norm_std is not None:
-        # models.py:636-637 normalises the image in predict(); the batched device path has no such stage
-        print(f"{FAIL} {model_cfg_path}: norm_mean / norm_std are not supported by the accelerated path.", flush=True)
-        sys.exit(1)
+    # models.py:636-637 normalises the image in predict(): the batched device path does it in front of the smooth prediction
+    model.handle.set_input_norm(model.norm_mean, model.norm_std)
+    detect_well = bool(getattr(args, "detect_well", False))
+    well_seed = int(getattr(args, "well_seed", 0) or 0)
 
     # ids are file stems, as in the reference (compute_branches.py:565-569: two files with one stem are one entry there too)
     ids = sorted(paths)
@@ -347,8 +344,19 @@ def main(args=None):
             width_um = img.shape[-1] * px
         return width_um
 
+    well_cache = {}
+
     def analyze_fn(batch, width_um, thresh, input_bits):
-        return branches.analyze_batch(model.handle, batch, config, width_um, model.ds_ratio, thresh=thresh, input_bits=input_bits)
+        if not detect_well:
+            return branches.analyze_batch(model.handle, batch, config, width_um, model.ds_ratio, thresh=thresh, input_bits=input_bits)
+        # --detect-well (compute_branches.py:318-337): the fields do not depend on the graph thresholds -- one staged pass per
+        # batch (run_sharded hands the same array to every configuration of the grid), then the graph stages per configuration
+        if well_cache.get("batch") is not batch:
+            well_cache.clear()
+            well_cache["batch"] = batch
+            well_cache["fields"] = branches.well_fields(model.handle, batch, model.ds_ratio, input_bits, well_seed,
+                                                        warn=lambda m: print(f"\033[93m[WARNING]\033[0m {m}", flush=True))
+        return branches.well_rows(model.handle, well_cache["fields"], config, width_um, thresh)
 
     vis = bool(getattr(args, "visualizations", False))
 

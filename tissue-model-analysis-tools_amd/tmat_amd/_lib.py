@@ -78,6 +78,10 @@ def lib():
     L.tmat_inv_depth_predict.argtypes = [vp, vp, i, vp, i, i, i, i, vp, vp]
     L.tmat_prof_enable.argtypes = [vp, i]
     L.tmat_set_precision.argtypes = [vp, i]
+    L.tmat_set_input_norm.argtypes = [vp, i, C.c_double, C.c_double]
+    L.tmat_preprocess_batch.argtypes = [vp, vp, i, i, i, C.c_double, vp]
+    L.tmat_well_threshold.argtypes = [vp, vp, i, i, vp]
+    L.tmat_canny_mask.argtypes = [vp, vp, i, i, C.c_double, vp]
     L.tmat_prof_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), i]
     for name in EXPORTS:
         fn = getattr(L, name)
@@ -92,7 +96,7 @@ EXPORTS = [
     "tmat_predict_smooth", "tmat_segment_batch", "tmat_postprocess_batch", "tmat_filter_edt_batch", "tmat_medial_axis_batch", "tmat_finish_batch", "tmat_filter_mask_batch", "tmat_zproj_batch", "tmat_zproj_dev", "tmat_gather_rows",
     "tmat_dmt_graph", "tmat_morse_stats",
     "tmat_analyze_batch_dev", "tmat_analyze_batch", "tmat_dev_alloc", "tmat_dev_free", "tmat_dev_upload",
-    "tmat_prof_enable", "tmat_prof_read", "tmat_set_precision", "tmat_host_lanczos4_u16", "tmat_host_rescale01_u16",
+    "tmat_prof_enable", "tmat_prof_read", "tmat_set_precision", "tmat_set_input_norm", "tmat_preprocess_batch", "tmat_well_threshold", "tmat_canny_mask", "tmat_host_lanczos4_u16", "tmat_host_rescale01_u16",
     "tmat_host_rescale255_f32", "tmat_host_filter_mask", "tmat_host_skeletonize", "tmat_host_medial_axis",
     "tmat_host_permutation", "tmat_host_postprocess",
     "tmat_set_gaussian_table", "tmat_host_gaussian_kernel1d", "tmat_gaussian_f32", "tmat_sato_batch", "tmat_stack_prepare", "tmat_vessel_field",
@@ -213,6 +217,11 @@ class Handle:
         out = np.empty((n, H, W), np.float64 if m >= 3 else np.uint16)
         check(lib().tmat_zproj_batch(self._h, ptr(a), n, Z, H, W, m, ptr(out)), "tmat_zproj_batch")
         return out.astype(stacks.dtype) if m < 3 else out
+
+    def set_input_norm(self, norm_mean=None, norm_std=None):
+        """models.py:636-637 on the device: x = (x - norm_mean) / norm_std in front of the smooth prediction; None turns it off"""
+        on = norm_mean is not None and norm_std is not None
+        check(lib().tmat_set_input_norm(self._h, int(on), float(norm_mean or 0.0), float(norm_std if on else 1.0)), "tmat_set_input_norm")
 
     def set_precision(self, mode="f32"):
         """arithmetic of the UNet's dense convolutions: "f32" (bit-exact contract, default) or "bf16x3" (opt-in split

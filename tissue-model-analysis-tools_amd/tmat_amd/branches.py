@@ -75,6 +75,55 @@ def analyze_batch(handle: _lib.Handle, imgs: np.ndarray, config: dict, image_wid
     return [(r.index, r.count, r.total_px, r.avg_px) for r in rows]
 
 
+def dsamp_shape(img_shape, width: int = DOWNSAMPLE_WIDTH):
+    """compute_branches.py:218-222: img_dsamp_res = round(shape * width / W)"""
+    r = width / img_shape[1]
+    return tuple(int(v) for v in np.round(np.multiply(img_shape[:2], r)).astype(int))
+
+
+def well_fields(handle: _lib.Handle, imgs: np.ndarray, ds_ratio: float = 0.625, input_bits: int = 16, well_seed: int = 0, warn=print):
+    """The 2-D branch of analyze_img with use_well_mask=True up to the vesselness field (compute_branches.py:309-361), image by
+    image through the staged GPU entry points: Lanczos + rescale (tmat_preprocess_batch) -> make_well_mask on THAT image
+    (:318-319, tmat_amd/well_mask_generation.py) -> predict(img * well_mask) (:328) -> (pred > 0.5) * well_mask ->
+    filter_branch_seg_mask (:334-337) -> medial axis, centre-line weighting of the unmasked prediction, resize (:340-357).
+    Returns [(field255 (fh, fw) f32, pruning_mask (fh, fw) bool, well_mask)] per image: the graph stages follow per threshold."""
+    from . import well_mask_generation as wmg
+    imgs = np.ascontiguousarray(imgs, np.uint16)
+    n, H, W = imgs.shape
+    hh, ww = int(round(W * ds_ratio)), int(round(H * ds_ratio))            # cv2 reads dsize as (width, height)
+    L = _lib.lib()
+    x = np.empty((n, hh, ww), np.float32)
+    _lib.check(L.tmat_set_input_depth(handle.raw, int(input_bits)), "tmat_set_input_depth")
+    _lib.check(L.tmat_preprocess_batch(handle.raw, _lib.ptr(imgs), n, H, W, float(ds_ratio), _lib.ptr(x)), "tmat_preprocess_batch")
+    _lib.check(L.tmat_set_input_depth(handle.raw, 16), "tmat_set_input_depth")
+    masks = [wmg.make_well_mask(x[i], handle=handle, seed=well_seed, warn=warn) for i in range(n)]
+    well = np.stack([m[0] for m in masks])
+    pred = handle.predict_smooth(x * well)                                  # img * well_mask: float32 * bool
+    filt = handle.filter_mask((pred > 0.5) & well)                          # seg_mask * well_mask, footprint disk(2), remove_isolated
+    skel, dist = handle.medial_axis(filt)
+    # the reference resizes to img_dsamp_res computed from the ORIGINAL image shape (:218-222)
+    fshape = dsamp_shape((H, W))
+    _, f255 = handle.finish(pred, dist, skel, fshape)
+    out = []
+    for i in range(n):
+        pruning = wmg._resize_nearest(np.logical_not(masks[i][1]), fshape).astype(bool)      # resize(order=0) (:359-361)
+        out.append((f255[i], pruning, well[i]))
+    return out
+
+
+def well_rows(handle: _lib.Handle, fields, config: dict, image_width_microns: float, thresh=(5.0, 10.0), first_index: int = 0):
+    """graph stages of the --detect-well form (compute_branches.py:391-457): DMT graph of the 0..255 field, MorseGraph with the
+    pruning mask -> rows (index, count, total_px, avg_px)"""
+    rows = []
+    for i, (f255, pruning, _) in enumerate(fields):
+        sw_px, min_px, max_px = graph_px_params(config, f255.shape[1], image_width_microns)
+        V, E = _lib.dmt_graph(f255, thresh[0], thresh[1], handle=handle)
+        _, cnt, tot, avg = _lib.morse_stats(V, E, f255.shape, sw_px, min_px, max_px, bool(config.get("remove_isolated_branches", False)),
+                                            pruning)
+        rows.append((first_index + i, cnt, tot, avg))
+    return rows
+
+
 def run_sharded(ids, load_fn, width_fn, analyze_fn, config: dict, rank: int = 0, world_size: int = 1, chunk: int = 64,
                 log=print):
     """The per-run driver of scripts/compute_branches.py (reference :585-594 loops over the images one by one):

@@ -85,26 +85,74 @@ def physical_pixel_sizes(path) -> PhysicalPixelSizes:
     return PhysicalPixelSizes(None, None, None)
 
 
+def page_layout(desc: str, n_pages: int):
+    """(size_t, size_z, size_c, order) of a multi-page TIFF from its ImageDescription, order = the page axes from the fastest
+    to the slowest varying one (e.g. "ZCT").  OME-XML: SizeT / SizeZ / SizeC / DimensionOrder of the first Pixels element;
+    ImageJ hyperstacks: frames= / slices= / channels=, always channel-fastest ("CZT").  Files without either convention are
+    one Z stack, as aicsimageio's plain TIFF reader presents them."""
+    m = re.search(r"<Pixels\b[^>]*>", desc or "")
+    if m:
+        attrs = dict(re.findall(r'(\w+)="([^"]*)"', m.group(0)))
+        try:
+            st, sz, sc = int(attrs.get("SizeT", 1)), int(attrs.get("SizeZ", 1)), int(attrs.get("SizeC", 1))
+        except ValueError:
+            st = sz = sc = 0
+        order = attrs.get("DimensionOrder", "XYZCT")[2:]
+        if st * sz * sc == n_pages and sorted(order) == ["C", "T", "Z"]:
+            return st, sz, sc, order
+    if "ImageJ=" in (desc or ""):
+        def num(key):
+            mm = re.search(key + r"=(\d+)", desc)
+            return int(mm.group(1)) if mm else 1
+        st, sz, sc = num("frames"), num("slices"), num("channels")
+        if st * sz * sc == n_pages:
+            return st, sz, sc, "CZT"
+    return 1, n_pages, 1, "ZCT"
+
+
 def load_image(file_path, T: Optional[int] = None, C: Optional[int] = None):
-    """(ZYX or YX array, PhysicalPixelSizes): the reference's contract (helper.py:23-120) for single files and for
-    lists of slice files.  Time series are not supported (T must be None or 0)."""
+    """(ZYX or YX array, PhysicalPixelSizes): the reference's contract (helper.py:23-95) for single files and for lists of
+    slice files, with its error messages: T / C must be given for time series / multi-channel files and lie in range.  The
+    page layout of multi-page files (which page is which T, Z, C) comes from the OME-XML or ImageJ description."""
     if isinstance(file_path, (list, tuple)):
         imgs, sizes = zip(*[load_image(fp, T, C) for fp in file_path])
         return np.array(imgs), sizes[0]
-    if T not in (None, 0):
-        raise ValueError(f"{file_path}: time-series files are not part of the accelerated path")
     from PIL import Image
     with Image.open(file_path) as im:
-        pages = []
-        for i in range(getattr(im, "n_frames", 1)):
-            im.seek(i)
-            pages.append(np.array(im))
-    out = []
-    for a in pages:
-        if a.ndim == 3:
-            if C is None:
-                raise ValueError(f"{file_path} is a multi channel image but no channel index was specified.")
-            a = a[..., C] if a.shape[-1] <= 4 else a[C]
-        out.append(a)
-    arr = out[0] if len(out) == 1 else np.stack(out)
+        n_pages = getattr(im, "n_frames", 1)
+        tags = dict(getattr(im, "tag_v2", {}) or {})
+        desc = tags.get(270, "")
+        if isinstance(desc, (tuple, list)):
+            desc = desc[0] if desc else ""
+        if isinstance(desc, bytes):
+            desc = desc.decode("utf8", "replace")
+        st, sz, sc, order = page_layout(desc, n_pages)
+        im.seek(0)
+        first = np.array(im)
+        interleaved = first.ndim == 3              # RGB(A) pages: the channel axis is inside the page
+        n_c = first.shape[-1] if interleaved else sc
+        if T is None:
+            if st > 1:
+                raise ValueError(f"{file_path} is a time series image but no time index was specified.")
+            T = 0
+        elif T >= st or T < 0:
+            raise ValueError(f"Time {T} is out of range for {file_path} with times: 0 - {st - 1}")
+        if C is None:
+            if n_c > 1:
+                raise ValueError(f"{file_path} is a multi channel image but no color channel index was specified.")
+            C = 0
+        elif C >= n_c or C < 0:
+            raise ValueError(f"Color channel {C} is out of range for {file_path} with color channels: 0 - {n_c - 1}")
+        sizes = {"T": st, "Z": sz, "C": sc}
+        stride, strides = 1, {}
+        for ax in order:
+            strides[ax] = stride
+            stride *= sizes[ax]
+        planes = []
+        for z in range(sz):
+            page = T * strides["T"] + z * strides["Z"] + (0 if interleaved else C) * strides["C"]
+            im.seek(page)
+            a = np.array(im)
+            planes.append(a[..., C] if interleaved else a)
+    arr = planes[0] if len(planes) == 1 else np.stack(planes)
     return arr, physical_pixel_sizes(file_path)

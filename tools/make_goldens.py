@@ -384,6 +384,89 @@ def gen_cellarea():
     print("cellarea.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items()})
 
 
+# --------------------------------------------------------------------------------------------
+# wellmask group: run under /opt/conda/bin/python3.9 (scikit-image 0.18.3).  The reference module
+# (fl_tissue_model_tools/well_mask_generation.py) is written against scikit-image 0.22; three API differences of the
+# 0.18.3 copy are bridged HERE, in the generator, never in the reference:
+#   * binary_erosion(image, footprint=...)  -> 0.18.3 spells the keyword `selem` (same function)
+#   * rescale / resize(order=0, preserve_range=True) -> from 0.19 on these are scipy.ndimage.zoom(order=0, grid_mode=True,
+#     mode="grid-constant"?) on the pixel-centre grid and keep a boolean input boolean (the module relies on that: it adds
+#     the result to a boolean array in place); the bridge makes exactly that scipy call.  [recalled from the 0.19+ source,
+#     which is not in this container]
+#   * the random superellipse search draws from the GLOBAL numpy generator without a seed: the generator seeds it
+#     (np.random.seed(seed)) before every call and stores the seed.
+# --------------------------------------------------------------------------------------------
+def wellmask_inputs():
+    """float32 images in [0, 1] like the ones compute_branches.py:316-319 hands to make_well_mask"""
+    from scipy import ndimage as ndi
+    out = {}
+    yy, xx = np.mgrid[0:640, 0:640].astype(np.float64)
+
+    def finish(a, seed):
+        rs = np.random.RandomState(seed)
+        a = ndi.gaussian_filter(a + rs.normal(0, 0.03, a.shape), 2.0)
+        a = (a - a.min()) / (a.max() - a.min())
+        return a.astype(np.float32)
+    out["round_bright"] = finish(((xx - 330) ** 2 + (yy - 310) ** 2 < 270 ** 2) * 0.6 + 0.2, 1)               # bright well, dark outside
+    out["round_dark"] = finish(0.8 - ((xx - 300) ** 2 + (yy - 335) ** 2 < 280 ** 2) * 0.5, 2)                 # dark well, bright outside
+    sq = (np.abs(xx - 320) / 285) ** 8 + (np.abs(yy - 320) / 285) ** 8 < 1
+    out["square_bright"] = finish(sq * 0.5 + 0.25, 3)                                                          # rounded-square well
+    a = np.full((480, 640), 0.5)
+    a[(xx[:480] - 320) ** 2 / 300.0 ** 2 + (yy[:480] - 240) ** 2 / 225.0 ** 2 < 1] = 0.9
+    out["nonsquare"] = finish(a, 4)
+    out["blank"] = np.full((320, 320), 0.25, np.float32)                                                        # no structure: fallback paths
+    return out
+
+
+def gen_wellmask():
+    import scipy.ndimage as ndi
+    import skimage.morphology
+    import skimage.transform
+    _shims()
+    _be = skimage.morphology.binary_erosion
+    skimage.morphology.binary_erosion = lambda image, footprint=None, **kw: _be(image, selem=footprint, **kw)
+
+    def _resize0(image, output_shape, order=None, preserve_range=False, **kw):
+        assert order == 0 and preserve_range
+        image = np.asarray(image)
+        zoom = [o / i for o, i in zip(output_shape, image.shape)]
+        src = image if image.dtype == bool else image.astype(np.float64)
+        out = ndi.zoom(src.astype(np.float64), zoom, order=0, mode="nearest", grid_mode=True)
+        return out.astype(bool) if image.dtype == bool else out
+
+    def _rescale0(image, scale, order=None, preserve_range=False, **kw):
+        shape = tuple(int(v) for v in np.round(np.asarray(image.shape) * scale))
+        return _resize0(image, shape, order=order, preserve_range=preserve_range)
+    skimage.transform.resize = _resize0
+    skimage.transform.rescale = _rescale0
+    from fl_tissue_model_tools import well_mask_generation as wm
+    out = {}
+    names = []
+    for name, img in wellmask_inputs().items():
+        for seed in (0, 7):
+            key = f"{name}_s{seed}"
+            out[key + "_thresh"] = np.packbits(wm.auto_threshold_well(img))
+            np.random.seed(seed)
+            res = wm.generate_well_mask(img, return_superellipse_params=True)
+            if isinstance(res, tuple):
+                mask, t, d, s_a, s_b, c_x, c_y, n = res
+                out[key + "_params"] = np.array([t, d, s_a, s_b, c_x, c_y, n], np.float64)
+            else:
+                mask = res
+                out[key + "_params"] = np.zeros(0)
+            out[key + "_mask"] = np.packbits(np.asarray(mask) > 0)
+            out[key + "_shape"] = np.array(img.shape, np.int64)
+            # mask_val = 255 form of compute_cell_area.py:127
+            np.random.seed(seed)
+            m255 = wm.generate_well_mask(img, mask_val=255)
+            assert np.array_equal(np.asarray(m255) > 0, np.asarray(mask) > 0)
+            names.append(key)
+            print(key, "coverage", float((np.asarray(mask) > 0).mean()), "params", out[key + "_params"])
+    out["names"] = np.array(names)
+    np.savez_compressed(GOLD / "wellmask.npz", **out)
+    print("wellmask.npz", len(names), "cases")
+
+
 if __name__ == "__main__":
     GOLD.mkdir(parents=True, exist_ok=True)
     _shims()
