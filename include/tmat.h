@@ -120,6 +120,8 @@ int tmat_preprocess_batch(tmat_handle h, const uint16_t *imgs, int n, int H, int
  * A handle from tmat_create_plain is enough.
  */
 int tmat_well_threshold(tmat_handle h, const float *img, int H, int W, uint8_t *out);
+/* the same for a float64 image: integer images (compute_cell_area.py:127) enter skimage's gaussian through img_as_float */
+int tmat_well_threshold_f64(tmat_handle h, const double *img, int H, int W, uint8_t *out);
 int tmat_canny_mask(tmat_handle h, const uint8_t *mask, int H, int W, double sigma, uint8_t *edges);
 
 /*
@@ -289,6 +291,20 @@ int tmat_field_stats(tmat_handle h, const float *field, int fh, int fw, float gr
  */
 int tmat_cell_area_batch(tmat_handle h, const uint16_t *imgs, int n, int H, int W, int out_h, int out_w, double sd_coef,
                          double *area, uint8_t *thresholded, double *params);
+
+/*
+ * The --detect-well form of the same tool (compute_cell_area.py:117-130, 273-286; preprocessing.exec_threshold with
+ * mask_idx): imgs (n, H, W) u16 are the ALREADY down-sampled images, masks (n, H, W) u8 their well masks
+ * (well_mask_generation.generate_well_mask(img, mask_val=255) > 0).  rescale_intensity uses the extrema of the whole image,
+ * the mixture is fitted to the pixels inside the mask only, pixels outside count as background.  area[i] = kept pixels /
+ * (H W): the caller divides by the well's pixel count (compute_area_prop with well_pix_area).
+ * tmat_resize_linear_u16 = the down-sampling step alone (compute_cell_area.py:54-57, cv2.resize with the default
+ * INTER_LINEAR; exactly halving both axes takes cv2's INTER_AREA shortcut (a + b + c + d + 2) >> 2): imgs (n, H, W) ->
+ * out (n, out_h, out_w), host buffers.
+ */
+int tmat_cell_area_masked(tmat_handle h, const uint16_t *imgs, const uint8_t *masks, int n, int H, int W, double sd_coef, double *area,
+                          uint8_t *thresholded, double *params);
+int tmat_resize_linear_u16(tmat_handle h, const uint16_t *imgs, int n, int H, int W, int out_h, int out_w, uint16_t *out);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Invasion-depth tool: reference scripts/compute_inv_depth.py:96-172, models.py:33-82 (build_ResNet50_TL),

@@ -62,6 +62,11 @@ def resize_linear_u16(img: np.ndarray, out_hw) -> np.ndarray:
     """cv2.resize(INTER_LINEAR) on uint16: horizontal pass then vertical pass in float32, saturating round-half-even store"""
     H, W = img.shape
     oh, ow = out_hw
+    if H == 2 * oh and W == 2 * ow:
+        # cv::resize switches INTER_LINEAR to the INTER_AREA fast path when both scale factors are exactly 2 (resize.cpp):
+        # integer mean of the 2 x 2 block, rounded half up
+        a = img.astype(np.uint32)
+        return ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint16)
     c0, c1, wc0, wc1 = linear_axis(W, ow)
     r0, r1, wr0, wr1 = linear_axis(H, oh)
     a = img.astype(np.float32)
@@ -127,13 +132,15 @@ def em_fit(levels: np.ndarray, counts: np.ndarray, resp0: np.ndarray):
     return w, mu, var, it, converged
 
 
-def gmm_threshold(img01: np.ndarray, sd_coef: float = 0.0, levels: np.ndarray = None):
-    """preprocessing.exec_threshold on the whole image: (foreground threshold, mask of pixels kept).  `levels`: the integer
-    image img01 was rescaled from; the 2-means initialisation then runs on the integer levels (exact integer sums, what the
-    device does) instead of on their float32 images -- the same partition up to float32 rounding of the values."""
-    vals, counts = np.unique(img01.ravel(), return_counts=True)
+def gmm_threshold(img01: np.ndarray, sd_coef: float = 0.0, levels: np.ndarray = None, mask: np.ndarray = None):
+    """preprocessing.exec_threshold: (foreground threshold, mask of pixels kept).  `levels`: the integer image img01 was
+    rescaled from; the 2-means initialisation then runs on the integer levels (exact integer sums, what the device does)
+    instead of on their float32 images -- the same partition up to float32 rounding of the values.  `mask` (the well,
+    compute_cell_area.py:81-85): the mixture is fitted to the pixels inside it, pixels outside are 0 (apply_mask)."""
+    sel = np.ones(img01.shape, bool) if mask is None else np.asarray(mask).astype(bool)
+    vals, counts = np.unique(img01[sel], return_counts=True)
     if levels is not None:
-        lv, lc = np.unique(levels.ravel(), return_counts=True)
+        lv, lc = np.unique(levels[sel], return_counts=True)
         assert len(lv) == len(vals) and np.array_equal(lc, counts)          # the rescale is strictly monotone
         k = two_means_threshold(lv.astype(np.float64), counts)
     else:
@@ -144,7 +151,8 @@ def gmm_threshold(img01: np.ndarray, sd_coef: float = 0.0, levels: np.ndarray = 
     w, mu, var, it, conv = em_fit(vals, counts, resp0)
     fg = int(np.argmax(mu))
     thresh = min(255.0, mu[fg] + math.sqrt(var[fg]) * sd_coef)
-    kept = np.where(img01 <= thresh, 0, img01) > 0
+    masked = np.where(sel, img01, 0)
+    kept = np.where(masked <= thresh, 0, masked) > 0
     return thresh, kept
 
 
@@ -156,3 +164,17 @@ def cell_area(img: np.ndarray, dsamp_size=512, sd_coef=0.0):
         img = resize_linear_u16(img.astype(np.uint16), resized_shape(img.shape, dsamp_size))
     thresh, kept = gmm_threshold(rescale01(img), sd_coef, levels=img)
     return kept.sum() / kept.size, kept.astype(np.uint8) * 255
+
+
+def cell_area_well(img: np.ndarray, dsamp_size=512, sd_coef=0.0, seed=0):
+    """--detect-well (compute_cell_area.py:117-130, 273-286): the well mask of the down-sampled image, the mixture inside it,
+    area relative to the well -> (area fraction, thresholded 0 / 255, well mask 0 / 255)"""
+    from . import wellmask
+    if img.ndim == 3:
+        img = img.max(0)
+    if dsamp_size is not None:
+        img = resize_linear_u16(img.astype(np.uint16), resized_shape(img.shape, dsamp_size))
+    well = np.asarray(wellmask.generate_well_mask(img, mask_val=255, seed=seed))
+    inside = well > 0
+    thresh, kept = gmm_threshold(rescale01(img), sd_coef, levels=img, mask=inside)
+    return kept.sum() / inside.sum(), kept.astype(np.uint8) * 255, well.astype(np.uint8)

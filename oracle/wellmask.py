@@ -35,6 +35,19 @@ def disk(radius: int) -> np.ndarray:
     return (X ** 2 + Y ** 2 <= radius ** 2).astype(np.uint8)
 
 
+def img_as_float(image: np.ndarray) -> np.ndarray:
+    """skimage.util.img_as_float as filters.gaussian applies it (util/dtype.py:_convert): floats pass, unsigned integers are
+    MULTIPLIED by 1 / max in float64"""
+    image = np.asarray(image)
+    if image.dtype in (np.float32, np.float64):
+        return image
+    if image.dtype == bool:
+        return image.astype(np.float64)
+    if image.dtype.kind == "u":
+        return np.multiply(image, 1.0 / np.iinfo(image.dtype).max, dtype=np.float64)
+    raise ValueError("img_as_float: unsigned integer or float images only")
+
+
 def rescale_0_255_u8(im: np.ndarray) -> np.ndarray:
     """rescale_intensity(im, out_range=(0, 255)).astype(uint8) for a float32 image (exposure.py:404-428 of 0.18.3)"""
     imin, imax = float(im.min()), float(im.max())
@@ -64,7 +77,7 @@ def threshold_otsu_u8(im: np.ndarray):
 def auto_threshold_well(image: np.ndarray) -> np.ndarray:
     """well_mask_generation.py:236-277"""
     image = np.asarray(image)
-    fimg = image if image.dtype in (np.float32, np.float64) else image.astype(np.float64)
+    fimg = img_as_float(image)
     im_blur = ndi.gaussian_filter(fimg, 1, mode="nearest", truncate=4.0)
     im_blur = rescale_0_255_u8(im_blur)
     ext = int(im_blur.min()), int(im_blur.max())

@@ -93,5 +93,68 @@ def test_script_end_to_end(tmp_path):
         oa, ok = ca.cell_area(imgs[name], 512, 0.25)
         assert float(pct) == oa * 100
         assert np.array_equal(np.array(Image.open(outd / "thresholded" / f"{name}_thresholded.png")), ok)
-    r = subprocess.run([sys.executable, str(script), str(ind), str(outd), "-w"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 1 and "detect-well" in r.stdout
+    # --detect-well: the same run with well masks (a second CSV next to the first: get_unique_output_filepath)
+    r = subprocess.run([sys.executable, str(script), str(ind), str(outd), "--sd-coef", "0.25", "-w", "--well-seed", "3"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = list(csv.reader(open(outd / "calculations" / "cell_area-2.csv")))
+    for name, pct in rows[1:]:
+        oa, ok, ow_ = ca.cell_area_well(imgs[name], 512, 0.25, seed=3)
+        assert float(pct) == oa * 100
+        assert np.array_equal(np.array(Image.open(outd / "thresholded" / f"{name}_thresholded-2.png")), ok)
+        assert np.array_equal(np.array(Image.open(outd / "thresholded" / f"{name}_well_mask.png")), ow_)
+
+
+def _well_plate(seed, shape=(600, 640), dtype=np.uint16):
+    """cells (bright blobs) inside a round well that is brighter than its surroundings"""
+    from scipy import ndimage as ndi
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+    inside = (xx - shape[1] * 0.5) ** 2 + (yy - shape[0] * 0.52) ** 2 < (min(shape) * 0.43) ** 2
+    a = np.where(inside, 0.35, 0.05) + rs.normal(0, 0.01, shape)
+    blobs = ndi.gaussian_filter((rs.uniform(size=shape) < 0.002).astype(float), 4) * 120
+    a = a + np.where(inside, blobs, 0)
+    top = 60000 if dtype == np.uint16 else 250
+    return np.clip(a / a.max() * top, 0, top).astype(dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.uint8])
+def test_detect_well_form_equals_the_oracle(dtype):
+    """--detect-well (compute_cell_area.py:117-130, 273-286): well mask of the down-sampled image, mixture inside it, area
+    relative to the well; equal to oracle/cellarea.py:cell_area_well, whose well mask is pinned to the reference"""
+    from oracle import cellarea as oc
+    from tmat_amd import _lib, preprocessing
+    h = _lib.Handle(None, 0)
+    try:
+        imgs = np.stack([_well_plate(1, dtype=dtype), _well_plate(2, dtype=dtype)])
+        area, kept, well = preprocessing.cell_area_batch_well(h, imgs, 512, 0.0, well_seed=7)
+    finally:
+        h.close()
+    for i in range(len(imgs)):
+        a0, k0, w0 = oc.cell_area_well(imgs[i], 512, 0.0, seed=7)
+        assert 0.3 < (w0 > 0).mean() < 0.9, "the test image should have a real well"
+        assert np.array_equal(well[i], w0)
+        assert np.array_equal(kept[i], k0)
+        assert area[i] == a0 and 0 < a0 < 1
+
+
+def test_exact_halving_takes_cv2s_area_path():
+    """cv2.resize(INTER_LINEAR) with both scale factors exactly 2 = INTER_AREA's (a + b + c + d + 2) >> 2 (resize.cpp): hand-derived
+    vectors, a 2 x 2 block summing to 4 k + 2 rounds UP (bilinear + round-half-even would round to even)"""
+    from oracle import cellarea as oc
+    from tmat_amd import _lib, preprocessing
+    img = np.array([[1, 2, 10, 10], [2, 1, 10, 11], [0, 0, 65535, 65535], [0, 1, 65535, 65534]], np.uint16)
+    want = np.array([[2, 10], [0, 65535]], np.uint16)           # (6 + 2) >> 2 = 2, (41 + 2) >> 2 = 10, (1 + 2) >> 2 = 0, (262139 + 2) >> 2 = 65535
+    assert np.array_equal(oc.resize_linear_u16(img, (2, 2)), want)
+    big = np.random.RandomState(0).randint(0, 65536, (3, 64, 64)).astype(np.uint16)
+    h = _lib.Handle(None, 0)
+    try:
+        got = preprocessing.resize_batch(h, big, 32)             # 64 x 64 -> 32 x 32: exactly 2 on both axes
+        odd = preprocessing.resize_batch(h, big, 40)             # not a halving: the bilinear path
+    finally:
+        h.close()
+    for i in range(3):
+        a = big[i].astype(np.uint32)
+        assert np.array_equal(got[i], ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint16))
+        assert np.array_equal(got[i], oc.resize_linear_u16(big[i], (32, 32)))
+        assert np.array_equal(odd[i], oc.resize_linear_u16(big[i], oc.resized_shape((64, 64), 40)))

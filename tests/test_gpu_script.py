@@ -165,4 +165,32 @@ def test_script_visualizations_and_time_refusal(tmp_path, handle, weights):
     seg = np.array(Image.open(vdir / "segmentation_mask.png"))
     assert set(np.unique(seg)) <= {0, 255} and seg.shape == pred.shape
     r = run([str(ind), str(tmp_path / "o2"), "--image-width-microns", "500", "--time", "2"])
-    assert r.returncode == 1 and "--time 2" in r.stdout
+    assert r.returncode == 1 and "Time 2 is out of range" in r.stdout          # the reference's message (helper.py:62-66)
+
+
+def test_script_time_series_tiff_and_detect_well(tmp_path, handle, weights):
+    """--time N picks the frame of a time-series TIFF (helper.load_image :57-84); -w / --detect-well runs the well-mask form
+    of the 2-D branch (compute_branches.py:318-337) with an explicit --well-seed: rows equal the staged API's"""
+    from PIL import Image, TiffImagePlugin
+    from tmat_amd import branches, synth
+    sys.path.insert(0, str(REPO / "tests"))
+    from test_gpu_wellmask import _well_image
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir()
+    frames = [synth.synth_image(40, 512, n_vessels=12, scale=1.0), _well_image(5)]
+    ifd = TiffImagePlugin.ImageFileDirectory_v2()
+    ifd[270] = "ImageJ=1.53\nimages=2\nframes=2\nhyperstack=true\n"
+    Image.fromarray(frames[0]).save(ind / "series.tif", save_all=True, append_images=[Image.fromarray(frames[1])], tiffinfo=ifd)
+    r = run([str(ind), str(outd), "--image-width-microns", "500"])
+    assert r.returncode == 1 and "time series image but no time index" in r.stdout
+    cfg = dict(graph_thresh_1=5, graph_thresh_2=10, graph_smoothing_window=12, min_branch_length=12)
+    for t, extra in ((0, []), (1, ["-w", "--well-seed", "7"])):
+        r = run([str(ind), str(outd / f"t{t}"), "--image-width-microns", "500", "--time", str(t)] + extra)
+        assert r.returncode == 0, r.stdout + r.stderr
+        rows = read_csv(outd / f"t{t}" / "branching_analysis.csv")
+        if extra:
+            want = branches.well_rows(handle, branches.well_fields(handle, frames[t][None], 0.625, 16, 7, warn=lambda m: None), cfg, 500.0)[0]
+        else:
+            want = branches.analyze_batch(handle, frames[t][None], cfg, 500.0)[0]
+        assert rows[1][0] == "series" and int(rows[1][1]) == want[1] and (want[1] > 0 or extra)
+        assert float(rows[1][2]) == pytest.approx(branches.pixels_to_microns(want[2], 384, 500.0), rel=1e-12)

@@ -31,11 +31,38 @@ __global__ __launch_bounds__(256) void resize_linear_u16_kernel(const uint16_t *
     }
 }
 
-__global__ __launch_bounds__(256) void hist_u16_kernel(const uint16_t *__restrict__ img, int npx, unsigned *__restrict__ hist)
+// cv::resize replaces INTER_LINEAR by INTER_AREA when both scale factors are exactly 2 (imgproc/src/resize.cpp: "if
+// (interpolation == INTER_LINEAR && is_area_fast && iscale_x == 2 && iscale_y == 2) interpolation = INTER_AREA"); the
+// INTER_AREA fast path for a 2 x 2 block is the integer mean rounded half up, (a + b + c + d + 2) >> 2
+__global__ __launch_bounds__(256) void resize_area2_u16_kernel(const uint16_t *__restrict__ img, int H, int W, uint16_t *__restrict__ out)
+{
+    const int oh = H / 2, ow = W / 2;
+    const uint16_t *src = img + (size_t)blockIdx.y * H * W;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < oh * ow; p += gridDim.x * 256) {
+        const int y = p / ow, x = p - y * ow;
+        const uint16_t *q = src + (size_t)(2 * y) * W + 2 * x;
+        out[(size_t)blockIdx.y * oh * ow + p] = (uint16_t)(((unsigned)q[0] + q[1] + q[W] + q[W + 1] + 2u) >> 2);
+    }
+}
+
+// mask (nullable): only pixels with mask != 0 are counted (exec_threshold fits the mixture to the pixels inside the well)
+__global__ __launch_bounds__(256) void hist_u16_kernel(const uint16_t *__restrict__ img, const uint8_t *__restrict__ mask, int npx, unsigned *__restrict__ hist)
 {
     const uint16_t *src = img + (size_t)blockIdx.y * npx;
+    const uint8_t *m = mask ? mask + (size_t)blockIdx.y * npx : nullptr;
     unsigned *h = hist + (size_t)blockIdx.y * 65536;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < npx; p += gridDim.x * 256) atomicAdd(&h[src[p]], 1u);
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npx; p += gridDim.x * 256) if (!m || m[p]) atomicAdd(&h[src[p]], 1u);
+}
+
+// lowest / highest level of the WHOLE image (rescale_intensity runs before the mask is applied): lohi[2 i] = min, [2 i + 1] = max,
+// initialised to 65536 / -1 by the host
+__global__ __launch_bounds__(256) void lohi_u16_kernel(const uint16_t *__restrict__ img, int npx, int *__restrict__ lohi)
+{
+    const uint16_t *src = img + (size_t)blockIdx.y * npx;
+    int lo = 65536, hi = -1;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < npx; p += gridDim.x * 256) { const int v = src[p]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+    for (int o = 32; o > 0; o >>= 1) { const int a = __shfl_down(lo, o), b = __shfl_down(hi, o); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+    if ((threadIdx.x & 63) == 0) { atomicMin(&lohi[2 * blockIdx.y], lo); atomicMax(&lohi[2 * blockIdx.y + 1], hi); }
 }
 
 // ---- block reductions over 1024 threads (16 waves) ----
@@ -63,7 +90,8 @@ constexpr double GMM_REG_COVAR = 1e-6, GMM_TOL = 1e-3;
 constexpr int GMM_MAX_ITER = 100;
 
 // params out per image: [0] threshold, [1..2] weights, [3..4] means, [5..6] variances, [7] iterations, [8] converged, [9] lo, [10] hi
-__global__ __launch_bounds__(1024) void gmm_hist_kernel(const unsigned *__restrict__ hist, double sd_coef, double *__restrict__ params)
+// lohi (nullable): the image extrema when the histogram only covers a mask; a histogram without pixels gives NaN parameters
+__global__ __launch_bounds__(1024) void gmm_hist_kernel(const unsigned *__restrict__ hist, double sd_coef, double *__restrict__ params, const int *__restrict__ lohi)
 {
     __shared__ double scratch[16 * 6];
     __shared__ long long s_n[16], s_s[16];
@@ -120,7 +148,7 @@ __global__ __launch_bounds__(1024) void gmm_hist_kernel(const unsigned *__restri
     __syncthreads();
     best = s_best[0]; bestk = s_bestk[0];
     for (int w = 1; w < 16; w++) if (s_best[w] > best || (s_best[w] == best && s_bestk[w] < bestk)) { best = s_best[w]; bestk = s_bestk[w]; }
-    const int lo = s_lo, hi = s_hi;
+    const int lo = lohi ? lohi[2 * blockIdx.x] : s_lo, hi = lohi ? lohi[2 * blockIdx.x + 1] : s_hi;
     const double dlo = (double)lo, drange = (double)hi - (double)lo;
     // pixel value of a level: rescale_intensity(img, (0, 1)).astype(float32)
     auto xval = [&](int level) -> double { return lo != hi ? (double)(float)(((double)level - dlo) / drange) : fmin(fmax((double)level, 0.0), 1.0); };
@@ -196,8 +224,8 @@ __global__ __launch_bounds__(1024) void gmm_hist_kernel(const unsigned *__restri
 }
 
 // gmm_masked = where(x <= thresh, 0, x); kept = gmm_masked > 0 -> 255 / 0, and the count of kept pixels
-__global__ __launch_bounds__(256) void apply_threshold_kernel(const uint16_t *__restrict__ img, int npx, const double *__restrict__ params,
-                                                              uint8_t *__restrict__ out, unsigned *__restrict__ kept)
+__global__ __launch_bounds__(256) void apply_threshold_kernel(const uint16_t *__restrict__ img, const uint8_t *__restrict__ mask, int npx,
+                                                              const double *__restrict__ params, uint8_t *__restrict__ out, unsigned *__restrict__ kept)
 {
     const double *p = params + (size_t)blockIdx.y * 11;
     const double thresh = p[0], lo = p[9], hi = p[10], range = hi - lo;
@@ -206,7 +234,7 @@ __global__ __launch_bounds__(256) void apply_threshold_kernel(const uint16_t *__
     for (int q = blockIdx.x * 256 + threadIdx.x; q < npx; q += gridDim.x * 256) {
         const double lv = (double)src[q];
         const double x = lo != hi ? (double)(float)((lv - lo) / range) : fmin(fmax(lv, 0.0), 1.0);
-        const bool k = !(x <= thresh) && x > 0.0;
+        const bool k = !(x <= thresh) && x > 0.0 && (!mask || mask[(size_t)blockIdx.y * npx + q]);      // apply_mask: outside the well the image is 0
         if (out) out[(size_t)blockIdx.y * npx + q] = k ? 255 : 0;
         local += k;
     }
@@ -234,9 +262,13 @@ static void linear_axis(int n_src, int n_dst, std::vector<int> &i0, std::vector<
 
 using namespace tmat;
 
-extern "C" int tmat_cell_area_batch(tmat_handle hd, const uint16_t *imgs, int n, int H, int W, int out_h, int out_w, double sd_coef, double *area,
-                                    uint8_t *thresholded, double *params)
+// masks (nullable): (n, oh, ow) u8 well masks on the DOWN-SAMPLED grid; small_out (nullable): the down-sampled images back to the host;
+// area = kept pixels / pixels (the caller divides by the well area when it masks)
+static int cell_area_impl(tmat_handle hd, const uint16_t *imgs, int n, int H, int W, int out_h, int out_w, double sd_coef, double *area,
+                          uint8_t *thresholded, double *params, const uint8_t *masks, uint16_t *small_out, int fit)
 {
+    uint8_t *dmaskbuf = nullptr;
+    int *lohibuf = nullptr;
     if (!hd || !imgs || !area || n < 0 || H < 1 || W < 1 || out_h < 0 || out_w < 0 || (out_h == 0) != (out_w == 0)) {
         set_error("tmat_cell_area_batch: bad argument");
         return TMAT_E_ARG;
@@ -277,20 +309,41 @@ extern "C" int tmat_cell_area_batch(tmat_handle hd, const uint16_t *imgs, int n,
             if (!ok) { set_error("tmat_cell_area_batch: table upload failed"); fail(TMAT_E_HIP); }
             else {
                 const int blocks = (oh * ow + 255) / 256;
-                hipLaunchKernelGGL(resize_linear_u16_kernel, dim3(blocks < 1024 ? blocks : 1024, n), dim3(256), 0, s, din, H, W, oh, ow, dr0, dr1, dwr0, dwr1, dc0, dc1,
-                                   dwc0, dwc1, dsm);
+                if (H == 2 * oh && W == 2 * ow)
+                    hipLaunchKernelGGL(resize_area2_u16_kernel, dim3(blocks < 1024 ? blocks : 1024, n), dim3(256), 0, s, din, H, W, dsm);
+                else
+                    hipLaunchKernelGGL(resize_linear_u16_kernel, dim3(blocks < 1024 ? blocks : 1024, n), dim3(256), 0, s, din, H, W, oh, ow, dr0, dr1, dwr0, dwr1, dc0, dc1,
+                                       dwc0, dwc1, dsm);
                 small = dsm;
             }
         }
     }
-    if (!rc) {
+    if (!rc && !fit) {          // tmat_resize_linear_u16: only the down-sampled images are wanted
+        if (!hip_ok(hipGetLastError(), "launch") || !hip_ok(hipMemcpyAsync(small_out, small, nout * 2, hipMemcpyDeviceToHost, s), "D2H") ||
+            !hip_ok(hipStreamSynchronize(s), "sync")) { hipStreamSynchronize(s); fail(TMAT_E_HIP); }
+    }
+    if (!rc && fit) {
         const int npx = oh * ow, blocks = (npx + 255) / 256;
         const dim3 grid(blocks < 512 ? blocks : 512, n);
         if (!hip_ok(hipMemsetAsync(hist, 0, (size_t)n * 65536 * 4, s), "memset") || !hip_ok(hipMemsetAsync(kept, 0, n * 4, s), "memset")) fail(TMAT_E_HIP);
         else {
-            hipLaunchKernelGGL(hist_u16_kernel, grid, dim3(256), 0, s, small, npx, hist);
-            hipLaunchKernelGGL(gmm_hist_kernel, dim3(n), dim3(1024), 0, s, hist, sd_coef, dpar);
-            hipLaunchKernelGGL(apply_threshold_kernel, grid, dim3(256), 0, s, small, npx, dpar, dthr, kept);
+            if (small_out && !hip_ok(hipMemcpyAsync(small_out, small, nout * 2, hipMemcpyDeviceToHost, s), "D2H")) fail(TMAT_E_HIP);
+            const uint8_t *dmask = nullptr;
+            int *lohi = nullptr;
+            if (!rc && masks) {
+                std::vector<int> init((size_t)2 * n);
+                for (int i = 0; i < n; i++) { init[2 * i] = 65536; init[2 * i + 1] = -1; }
+                if (!hip_ok(hipMalloc((void **)&dmaskbuf, nout), "hipMalloc") || !hip_ok(hipMalloc((void **)&lohibuf, (size_t)2 * n * 4), "hipMalloc") ||
+                    !hip_ok(hipMemcpyAsync(dmaskbuf, masks, nout, hipMemcpyHostToDevice, s), "H2D") ||
+                    !hip_ok(hipMemcpy(lohibuf, init.data(), init.size() * 4, hipMemcpyHostToDevice), "H2D")) fail(TMAT_E_HIP);
+                else {
+                    dmask = dmaskbuf; lohi = lohibuf;
+                    hipLaunchKernelGGL(lohi_u16_kernel, grid, dim3(256), 0, s, small, npx, lohi);
+                }
+            }
+            hipLaunchKernelGGL(hist_u16_kernel, grid, dim3(256), 0, s, small, dmask, npx, hist);
+            hipLaunchKernelGGL(gmm_hist_kernel, dim3(n), dim3(1024), 0, s, hist, sd_coef, dpar, lohi);
+            hipLaunchKernelGGL(apply_threshold_kernel, grid, dim3(256), 0, s, small, dmask, npx, dpar, dthr, kept);
             std::vector<unsigned> kh(n);
             std::vector<double> ph((size_t)n * 11);
             if (!hip_ok(hipGetLastError(), "launch") || !hip_ok(hipMemcpyAsync(kh.data(), kept, n * 4, hipMemcpyDeviceToHost, s), "D2H") ||
@@ -303,6 +356,26 @@ extern "C" int tmat_cell_area_batch(tmat_handle hd, const uint16_t *imgs, int n,
             }
         }
     }
-    hipFree(din); hipFree(dsm); hipFree(hist); hipFree(kept); hipFree(dpar); hipFree(dthr); hipFree(itab); hipFree(ftab);
+    hipFree(din); hipFree(dsm); hipFree(hist); hipFree(kept); hipFree(dpar); hipFree(dthr); hipFree(itab); hipFree(ftab); hipFree(dmaskbuf); hipFree(lohibuf);
     return rc;
+}
+
+extern "C" int tmat_cell_area_batch(tmat_handle hd, const uint16_t *imgs, int n, int H, int W, int out_h, int out_w, double sd_coef, double *area,
+                                    uint8_t *thresholded, double *params)
+{
+    return cell_area_impl(hd, imgs, n, H, W, out_h, out_w, sd_coef, area, thresholded, params, nullptr, nullptr, 1);
+}
+
+extern "C" int tmat_cell_area_masked(tmat_handle hd, const uint16_t *imgs, const uint8_t *masks, int n, int H, int W, double sd_coef, double *area,
+                                     uint8_t *thresholded, double *params)
+{
+    if (!masks) { set_error("tmat_cell_area_masked: null masks"); return TMAT_E_ARG; }
+    return cell_area_impl(hd, imgs, n, H, W, 0, 0, sd_coef, area, thresholded, params, masks, nullptr, 1);
+}
+
+extern "C" int tmat_resize_linear_u16(tmat_handle hd, const uint16_t *imgs, int n, int H, int W, int out_h, int out_w, uint16_t *out)
+{
+    if (!out || out_h < 1 || out_w < 1) { set_error("tmat_resize_linear_u16: bad argument"); return TMAT_E_ARG; }
+    std::vector<double> area((size_t)(n > 0 ? n : 1));
+    return cell_area_impl(hd, imgs, n, H, W, out_h, out_w, 0.0, area.data(), nullptr, nullptr, nullptr, out, 0);
 }

@@ -286,17 +286,19 @@ int tmat_gaussian_f32(tmat_handle hd, const float *x, int d0, int d1, int d2, do
     return TMAT_OK;
 }
 
-/* well_mask_generation.auto_threshold_well (reference :236-277) on the device: img (H, W) f32 -> thresholded, eroded mask u8 */
-int tmat_well_threshold(tmat_handle hd, const float *img, int H, int W, uint8_t *out)
+/* well_mask_generation.auto_threshold_well (reference :236-277) on the device: img (H, W) -> thresholded, eroded mask u8.
+ * is_f64 = 0: a float32 image (what compute_branches.py hands over); 1: float64 (integer images after img_as_float) */
+static int well_threshold(tmat_handle hd, const void *img, int is_f64, int H, int W, uint8_t *out)
 {
     Ctx *c = (Ctx *)hd;
-    if (!c || !img || !out || H < 20 || W < 20 || (long long)H * W > (1LL << 30)) { set_error("tmat_well_threshold: bad argument (images of at least 20 x 20)"); return TMAT_E_ARG; }
+    if (!c || !img || !out || H < 20 || W < 20 || (long long)H * W > (1LL << 28)) { set_error("tmat_well_threshold: bad argument (images of at least 20 x 20)"); return TMAT_E_ARG; }
     TMAT_HIP(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const size_t n = (size_t)H * W;
     Arena A;
     A.drain = s;
-    float *a = A.get<float>(n), *b = A.get<float>(n), *mm = A.get<float>(2);
+    float *a = A.get<float>(is_f64 ? 1 : n), *b = A.get<float>(is_f64 ? 1 : n), *mm = A.get<float>(2);
+    double *da = A.get<double>(is_f64 ? n : 1), *db = A.get<double>(is_f64 ? n : 1), *dmm = A.get<double>(2);
     uint8_t *u8 = A.get<uint8_t>(n), *th = A.get<uint8_t>(n), *er = A.get<uint8_t>(n);
     unsigned *hist = A.get<unsigned>(5 * 256);
     int *decision = A.get<int>(2), *offs = A.get<int>(2 * 81);
@@ -304,12 +306,22 @@ int tmat_well_threshold(tmat_handle hd, const float *img, int H, int W, uint8_t 
     int o[2 * 81], k = 0;
     for (int dy = -5; dy <= 5; dy++) for (int dx = -5; dx <= 5; dx++) if (dy * dy + dx * dx <= 25) { o[2 * k] = dy; o[2 * k + 1] = dx; k++; }     // disk(5): 81
     TMAT_HIP(hipMemcpyAsync(offs, o, sizeof(int) * 2 * k, hipMemcpyHostToDevice, s));
-    TMAT_HIP(hipMemcpyAsync(a, img, n * 4, hipMemcpyHostToDevice, s));
-    // gaussian(image, sigma=1): ndi.gaussian_filter, mode 'nearest', truncate 4, float32 after each axis
-    if (!gauss_pass_f32(c, a, b, Pass{1.0, 0, H, W, 1}, 4.0, EXT_NEAREST, s) || !gauss_pass_f32(c, b, a, Pass{1.0, 0, W, 1, (size_t)H}, 4.0, EXT_NEAREST, s))
-        return TMAT_E_HIP;
-    launch_minmax_f32(a, 1, n, mm, mm + 1, s);
-    launch_wm_rescale_u8(a, n, mm, mm + 1, u8, s);
+    // gaussian(image, sigma=1): ndi.gaussian_filter, mode 'nearest', truncate 4, the image's float type after each axis
+    if (is_f64) {
+        TMAT_HIP(hipMemcpyAsync(da, img, n * 8, hipMemcpyHostToDevice, s));
+        const GaussTable &gt = gauss_table(c, 1.0, 0, gauss_radius(1.0, 4.0));
+        const double *w = table_dev(c, gt);
+        if (!w) return TMAT_E_HIP;
+        launch_corr1d_f64(da, db, 1, H, W, w, gt.r, gt.sym, EXT_NEAREST, s);
+        launch_corr1d_f64(db, da, (size_t)H, W, 1, w, gt.r, gt.sym, EXT_NEAREST, s);
+        launch_wm_rescale_u8_f64(da, n, dmm, u8, s);
+    } else {
+        TMAT_HIP(hipMemcpyAsync(a, img, n * 4, hipMemcpyHostToDevice, s));
+        if (!gauss_pass_f32(c, a, b, Pass{1.0, 0, H, W, 1}, 4.0, EXT_NEAREST, s) || !gauss_pass_f32(c, b, a, Pass{1.0, 0, W, 1, (size_t)H}, 4.0, EXT_NEAREST, s))
+            return TMAT_E_HIP;
+        launch_minmax_f32(a, 1, n, mm, mm + 1, s);
+        launch_wm_rescale_u8(a, n, mm, mm + 1, u8, s);
+    }
     launch_wm_hist(u8, H, W, hist, s);
     launch_wm_decide(hist, H, W, decision, s);
     launch_wm_threshold(u8, n, decision, th, s);
@@ -319,6 +331,9 @@ int tmat_well_threshold(tmat_handle hd, const float *img, int H, int W, uint8_t 
     TMAT_HIP(hipStreamSynchronize(s));
     return TMAT_OK;
 }
+
+int tmat_well_threshold(tmat_handle hd, const float *img, int H, int W, uint8_t *out) { return well_threshold(hd, img, 0, H, W, out); }
+int tmat_well_threshold_f64(tmat_handle hd, const double *img, int H, int W, uint8_t *out) { return well_threshold(hd, img, 1, H, W, out); }
 
 /* skimage.feature.canny(mask, sigma) of a boolean image with the default thresholds (reference calls:
  * well_mask_generation.py:165, :201): mask (H, W) u8 -> edges u8 */

@@ -5,6 +5,8 @@
 namespace tmat {
 // rescale_intensity(blur, out_range=(0, 255)).astype(uint8) of a float32 image whose extrema are mn[0], mx[0] (device)
 void launch_wm_rescale_u8(const float *blur, size_t n, const float *mn, const float *mx, uint8_t *out, hipStream_t s);
+// the same for a float64 image; mm: 2 doubles of device scratch (extrema are computed here)
+void launch_wm_rescale_u8_f64(const double *blur, size_t n, double *mm, uint8_t *out, hipStream_t s);
 // hist: 5 x 256 counts (whole image, then the four 5 % corners: top-left, top-right, bottom-left, bottom-right); zeroed here
 void launch_wm_hist(const uint8_t *img, int H, int W, unsigned *hist, hipStream_t s);
 // decision[0] = Otsu threshold of the (possibly inverted) image, decision[1] = invert flag (auto_threshold_well :244-273)

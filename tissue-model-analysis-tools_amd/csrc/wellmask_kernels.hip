@@ -39,6 +39,40 @@ void launch_wm_rescale_u8(const float *blur, size_t n, const float *mn, const fl
     hipLaunchKernelGGL(wm_rescale_u8_kernel, wm_grid(n), dim3(256), 0, s, blur, n, mn, mx, out);
 }
 
+// the float64 form (integer images reach gaussian() through img_as_float -> float64): extrema by one workgroup, then the rescale
+__global__ __launch_bounds__(1024) void wm_minmax_f64_kernel(const double *__restrict__ x, size_t n, double *__restrict__ mm)
+{
+    __shared__ double smn[16], smx[16];
+    double lo = __builtin_inf(), hi = -__builtin_inf();
+    for (size_t p = threadIdx.x; p < n; p += 1024) { const double v = x[p]; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+    for (int o = 32; o > 0; o >>= 1) { const double a = __shfl_down(lo, o), b = __shfl_down(hi, o); lo = a < lo ? a : lo; hi = b > hi ? b : hi; }
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = lo; smx[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++) { lo = smn[w] < lo ? smn[w] : lo; hi = smx[w] > hi ? smx[w] : hi; }
+        mm[0] = lo; mm[1] = hi;
+    }
+}
+__global__ void wm_rescale_u8_f64_kernel(const double *__restrict__ x, size_t n, const double *__restrict__ mm, uint8_t *__restrict__ out)
+{
+    const double lo = mm[0], hi = mm[1], rng = hi - lo;
+    WM_LOOP(p, n) {
+        double v = fmin(fmax(x[p], lo), hi);
+        if (lo != hi) {
+            v = (v - lo) / rng;
+            v = v * 255.0 + 0.0;
+        } else {
+            v = fmin(fmax(v, 0.0), 255.0);
+        }
+        out[p] = (uint8_t)(int)v;
+    }
+}
+void launch_wm_rescale_u8_f64(const double *blur, size_t n, double *mm, uint8_t *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(wm_minmax_f64_kernel, dim3(1), dim3(1024), 0, s, blur, n, mm);
+    hipLaunchKernelGGL(wm_rescale_u8_f64_kernel, wm_grid(n), dim3(256), 0, s, blur, n, mm, out);
+}
+
 __global__ __launch_bounds__(256) void wm_hist_kernel(const uint8_t *__restrict__ img, int H, int W, unsigned *__restrict__ hist)
 {
     __shared__ unsigned h[5 * 256];

@@ -123,11 +123,18 @@ def n_planes(path: str) -> int:
         a = np.load(path, mmap_mode="r")
         return a.shape[0] if a.ndim == 3 and a.shape[0] > 4 and a.shape[-1] > 4 else 1
     from PIL import Image
+    from tmat_amd import helper
     try:
         with Image.open(path) as im:
-            return getattr(im, "n_frames", 1)
+            n = getattr(im, "n_frames", 1)
+            desc = dict(getattr(im, "tag_v2", {}) or {}).get(270, "")
     except OSError:
         return 1
+    if isinstance(desc, (tuple, list)):
+        desc = desc[0] if desc else ""
+    if isinstance(desc, bytes):
+        desc = desc.decode("utf8", "replace")
+    return helper.page_layout(desc, n)[1]            # SizeZ: pages of a time series or of channels are not Z slices
 
 
 def find_inputs(in_root: Path):
@@ -207,6 +214,11 @@ def finish_distributed(ws: int):
 def run_stacks(args, config, paths, out_root: Path, rank: int, ws: int, local_rank: int):
     """Z-stack entries: the Sato branch (compute_branches.py:224-306) on this rank's share of the stacks"""
     from tmat_amd import _lib, branches, helper, sato
+    if getattr(args, "detect_well", False):
+        # compute_branches.py:231-243 makes the stack's well mask from a float64 anti-aliased resize of the max projection; that
+        # input is not produced by this path yet (the 2-D branch and compute_cell_area.py accept -w)
+        print(f"{FAIL} --detect-well is not available for Z-stack inputs in the accelerated path.", flush=True)
+        sys.exit(1)
     handle = _lib.Handle(None, local_rank)          # this branch needs no segmentation model
     hessian = getattr(args, "sato_hessian", "gaussian_derivatives")
     vis = bool(getattr(args, "visualizations", False))

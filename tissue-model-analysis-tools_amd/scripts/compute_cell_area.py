@@ -40,6 +40,8 @@ def parse_cell_area_args(argv=None):
     p.add_argument("--channel", type=int, default=None)
     p.add_argument("--time", type=int, default=None)
     p.add_argument("-w", "--detect-well", action="store_true")
+    p.add_argument("--well-seed", type=int, default=0,
+                   help="seed of the random superellipse search of --detect-well (unseeded in the reference, well_mask_generation.py:35)")
     p.add_argument("--sd-coef", type=float, default=None)
     p.add_argument("-c", "--config", type=str, default=DEFAULT_CONFIG_PATH)
     args = p.parse_args(argv)
@@ -68,9 +70,6 @@ def main(argv=None):
         sys.exit(1)
     if not glob(str(in_root / "*")):
         print(f"{FAIL}No images found in {in_root}", flush=True)
-        sys.exit(1)
-    if args.detect_well:
-        print(f"{FAIL} --detect-well is not available in the accelerated path (unseeded random search in the reference).", flush=True)
         sys.exit(1)
     paths, is_stack = find_inputs(in_root)
     if not paths:
@@ -105,11 +104,17 @@ def main(argv=None):
         print(f"{WARN} Input images are Z stacks. Creating maximum intensity Z projections prior to cell area calculation.", flush=True)
     img_ids = sorted(paths)                     # a deterministic order: the ranks must agree on it (the reference keeps glob order)
     mine = [img_ids[int(i)] for i in distributed.shard_indices(len(img_ids), rank, ws)]
-    areas, kept_all = {}, {}
+    areas, kept_all, wells = {}, {}, {}
 
     def flush(group):
-        for shape, items in group.items():
-            area, kept = preprocessing.cell_area_batch(handle, np.stack([im for _, im in items]), dsamp_size, sd_coef)
+        for (shape, dtype), items in group.items():          # one dtype per batch: np.stack would silently widen a mixed group
+            batch = np.stack([im for _, im in items])
+            if args.detect_well:
+                area, kept, well = preprocessing.cell_area_batch_well(handle, batch, dsamp_size, sd_coef, args.well_seed)
+                for (img_id, _), wm_ in zip(items, well):
+                    wells[img_id] = wm_
+            else:
+                area, kept = preprocessing.cell_area_batch(handle, batch, dsamp_size, sd_coef)
             for (img_id, _), a, k in zip(items, area, kept):
                 areas[img_id], kept_all[img_id] = a, k
 
@@ -124,7 +129,7 @@ def main(argv=None):
             except (OSError, ValueError) as error:
                 print(f"{FAIL}{error}", flush=True)
                 sys.exit(1)
-            group.setdefault(img.shape, []).append((img_id, img))
+            group.setdefault((img.shape, img.dtype.str), []).append((img_id, img))
         flush(group)
     print("... Areas computed successfully.", flush=True)
     print(OK, flush=True)
@@ -132,6 +137,8 @@ def main(argv=None):
     out_ids = [i.replace("/", "_").replace("\\", "_") for i in img_ids]
     for img_id in mine:
         oid = out_ids[img_ids.index(img_id)]
+        if args.detect_well:                                   # compute_cell_area.py:301-306
+            Image.fromarray(wells[img_id]).save(get_unique_output_filepath(out_root / THRESH_SUBDIR / f"{oid}_well_mask.png"))
         file = get_unique_output_filepath(out_root / THRESH_SUBDIR / f"{oid}_thresholded.png")
         Image.fromarray(kept_all[img_id]).save(file)
     index_of = {img_id: i for i, img_id in enumerate(img_ids)}
@@ -141,6 +148,8 @@ def main(argv=None):
         handle.close()
         distributed.finish_process_group()
         return
+    if args.detect_well:
+        print(f"... Well masks saved to:{os.linesep}\t{out_root}/{THRESH_SUBDIR}", flush=True)
     print(f"... Thresholded images saved to:{os.linesep}\t{out_root}/{THRESH_SUBDIR}", flush=True)
     area_out_path = get_unique_output_filepath(out_root / CALC_SUBDIR / "cell_area.csv")
     with open(area_out_path, "w", newline="") as f:           # pandas DataFrame.to_csv(index=False): header + repr of the floats

@@ -73,6 +73,8 @@ def lib():
     L.tmat_analyze_stack.argtypes = [vp, vp, i, i, i, i, i, f, f, i, i, i, i, C.c_int64, vp, vp]
     L.tmat_field_stats.argtypes = [vp, vp, i, i, f, f, i, i, i, i, C.c_int64, vp]
     L.tmat_cell_area_batch.argtypes = [vp, vp, i, i, i, i, i, d, vp, vp, vp]
+    L.tmat_cell_area_masked.argtypes = [vp, vp, vp, i, i, i, d, vp, vp, vp]
+    L.tmat_resize_linear_u16.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.tmat_resnet_load.argtypes = [vp, vp, sz, C.POINTER(i)]
     L.tmat_resnet_predict.argtypes = [vp, i, vp, i, i, vp]
     L.tmat_inv_depth_predict.argtypes = [vp, vp, i, vp, i, i, i, i, vp, vp]
@@ -81,6 +83,7 @@ def lib():
     L.tmat_set_input_norm.argtypes = [vp, i, C.c_double, C.c_double]
     L.tmat_preprocess_batch.argtypes = [vp, vp, i, i, i, C.c_double, vp]
     L.tmat_well_threshold.argtypes = [vp, vp, i, i, vp]
+    L.tmat_well_threshold_f64.argtypes = [vp, vp, i, i, vp]
     L.tmat_canny_mask.argtypes = [vp, vp, i, i, C.c_double, vp]
     L.tmat_prof_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double), i]
     for name in EXPORTS:
@@ -96,11 +99,11 @@ EXPORTS = [
     "tmat_predict_smooth", "tmat_segment_batch", "tmat_postprocess_batch", "tmat_filter_edt_batch", "tmat_medial_axis_batch", "tmat_finish_batch", "tmat_filter_mask_batch", "tmat_zproj_batch", "tmat_zproj_dev", "tmat_gather_rows",
     "tmat_dmt_graph", "tmat_morse_stats",
     "tmat_analyze_batch_dev", "tmat_analyze_batch", "tmat_dev_alloc", "tmat_dev_free", "tmat_dev_upload",
-    "tmat_prof_enable", "tmat_prof_read", "tmat_set_precision", "tmat_set_input_norm", "tmat_preprocess_batch", "tmat_well_threshold", "tmat_canny_mask", "tmat_host_lanczos4_u16", "tmat_host_rescale01_u16",
+    "tmat_prof_enable", "tmat_prof_read", "tmat_set_precision", "tmat_set_input_norm", "tmat_preprocess_batch", "tmat_well_threshold", "tmat_well_threshold_f64", "tmat_canny_mask", "tmat_host_lanczos4_u16", "tmat_host_rescale01_u16",
     "tmat_host_rescale255_f32", "tmat_host_filter_mask", "tmat_host_skeletonize", "tmat_host_medial_axis",
     "tmat_host_permutation", "tmat_host_postprocess",
     "tmat_set_gaussian_table", "tmat_host_gaussian_kernel1d", "tmat_gaussian_f32", "tmat_sato_batch", "tmat_stack_prepare", "tmat_vessel_field",
-    "tmat_analyze_stack", "tmat_field_stats", "tmat_cell_area_batch",
+    "tmat_analyze_stack", "tmat_field_stats", "tmat_cell_area_batch", "tmat_cell_area_masked", "tmat_resize_linear_u16",
     "tmat_resnet_load", "tmat_resnet_predict", "tmat_inv_depth_predict",
 ]
 

@@ -36,6 +36,40 @@ def cell_area_batch(handle: Handle, imgs: np.ndarray, dsamp_size=512, sd_coef: f
     return (area, out, params) if return_params else (area, out)
 
 
+def resize_batch(handle: Handle, imgs: np.ndarray, dsamp_size) -> np.ndarray:
+    """the down-sampling step of load_img (compute_cell_area.py:54-57) for a batch, on the device: (n, H, W) -> (n, h, w) uint16"""
+    a = np.ascontiguousarray(imgs, np.uint16)
+    n, H, W = a.shape
+    oh, ow = resized_shape((H, W), dsamp_size)
+    out = np.empty((n, oh, ow), np.uint16)
+    check(lib().tmat_resize_linear_u16(handle.raw, ptr(a), n, H, W, oh, ow, ptr(out)), "tmat_resize_linear_u16")
+    return out
+
+
+def cell_area_batch_well(handle: Handle, imgs: np.ndarray, dsamp_size=512, sd_coef: float = 0.0, well_seed: int = 0):
+    """--detect-well form (compute_cell_area.py:117-130, 273-286): down-sample, well mask of every down-sampled image
+    (generate_well_mask(img, mask_val=255)), mixture fitted inside the mask, area relative to the well's pixel count.
+    -> (area fractions (n,), thresholded (n, h, w) uint8 0 / 255, well masks (n, h, w) uint8 0 / 255)"""
+    from . import well_mask_generation as wmg
+    a = np.asarray(imgs)
+    if a.ndim != 3 or a.dtype not in (np.uint8, np.uint16):
+        raise ValueError("cell_area_batch_well: expected (n, H, W) uint8 or uint16 images")
+    src_dtype = a.dtype
+    small = resize_batch(handle, a, dsamp_size) if dsamp_size is not None else np.ascontiguousarray(a, np.uint16)
+    n, h, w = small.shape
+    # the reference makes the mask from the image in its own dtype (uint8 images stay uint8 through cv2.resize)
+    masks = np.stack([np.asarray(wmg.generate_well_mask(small[i].astype(src_dtype), mask_val=255, handle=handle, seed=well_seed)) for i in range(n)])
+    m8 = np.ascontiguousarray(masks > 0, np.uint8)
+    area = np.empty(n, np.float64)
+    out = np.empty((n, h, w), np.uint8)
+    params = np.empty((n, 9), np.float64)
+    check(lib().tmat_cell_area_masked(handle.raw, ptr(small), ptr(m8), n, h, w, float(sd_coef), ptr(area), ptr(out), ptr(params)), "tmat_cell_area_masked")
+    # compute_area_prop(img, well_pix_area): np.sum(img > 0) / ref_area, from the integer counts
+    kept_px = (out > 0).reshape(n, -1).sum(1)
+    well_px = m8.reshape(n, -1).sum(1)
+    return kept_px / well_px, out, masks.astype(np.uint8)
+
+
 def exec_threshold(handle: Handle, img: np.ndarray, sd_coef: float = 0.0) -> np.ndarray:
     """preprocessing.exec_threshold for one integer image without a well mask: the image with background pixels set to 0"""
     area, kept = cell_area_batch(handle, np.asarray(img)[None], None, sd_coef)

@@ -105,12 +105,23 @@ def _border(handle, mask: np.ndarray) -> np.ndarray:
 
 def auto_threshold_well(image: np.ndarray, handle: _lib.Handle) -> np.ndarray:
     """Threshold an image to get a rough mask of the well (reference :236-277), on the GPU"""
-    img = np.ascontiguousarray(image, np.float32)
-    if img.ndim != 2:
+    image = np.asarray(image)
+    if image.ndim != 2:
         raise ValueError("auto_threshold_well: 2-D image expected")
     ensure_gaussian_table(handle, 1.0, 0, 4.0)
-    out = np.empty(img.shape, np.uint8)
-    _lib.check(_lib.lib().tmat_well_threshold(handle.raw, _lib.ptr(img), img.shape[0], img.shape[1], _lib.ptr(out)), "tmat_well_threshold")
+    out = np.empty(image.shape, np.uint8)
+    if image.dtype == np.float32:
+        img = np.ascontiguousarray(image)
+        _lib.check(_lib.lib().tmat_well_threshold(handle.raw, _lib.ptr(img), img.shape[0], img.shape[1], _lib.ptr(out)), "tmat_well_threshold")
+    else:
+        # skimage's gaussian() converts with img_as_float: unsigned integers are multiplied by 1 / max in float64
+        if image.dtype.kind == "u":
+            img = np.multiply(image, 1.0 / np.iinfo(image.dtype).max, dtype=np.float64)
+        elif image.dtype == np.float64:
+            img = np.ascontiguousarray(image)
+        else:
+            raise ValueError("auto_threshold_well: float32 / float64 / unsigned integer images")
+        _lib.check(_lib.lib().tmat_well_threshold_f64(handle.raw, _lib.ptr(img), img.shape[0], img.shape[1], _lib.ptr(out)), "tmat_well_threshold_f64")
     return out.astype(bool)
 
 

@@ -415,6 +415,9 @@ def wellmask_inputs():
     a[(xx[:480] - 320) ** 2 / 300.0 ** 2 + (yy[:480] - 240) ** 2 / 225.0 ** 2 < 1] = 0.9
     out["nonsquare"] = finish(a, 4)
     out["blank"] = np.full((320, 320), 0.25, np.float32)                                                        # no structure: fallback paths
+    # integer images, as compute_cell_area.py:127 hands them over (gaussian() then converts with img_as_float)
+    out["round_u16"] = (out["round_dark"][::2, ::2] * 60000.0 + 1500.0).astype(np.uint16)
+    out["square_u8"] = (out["square_bright"][::2, ::2] * 250.0).astype(np.uint8)
     return out
 
 
