@@ -128,3 +128,44 @@ def test_gather_rows_ragged_world2(tmp_path):
     script.write_text(RAGGED.format(repo=str(REPO)))
     assert _run(script, [], 2).count("ok") == 2
     assert _run(script, [], 1).count("ok") == 1
+
+
+FAILING = r"""
+import sys
+sys.path.insert(0, r"{repo}"); sys.path.insert(0, r"{repo}/tissue-model-analysis-tools_amd")
+import numpy as np
+from tmat_amd import branches, distributed
+ws, rank, _ = distributed.init_process_group_from_env()
+ids = ["img%02d" % i for i in range(6)]
+def load_fn(i):
+    if i == "img04":                       # lies in the LAST rank's shard: the first rank finishes its work and waits in the gather
+        print("cannot read", i, flush=True)
+        raise branches.InputError(i)
+    return np.full((8, 8), int(i[3:]), np.uint16)
+try:
+    branches.run_sharded(ids, load_fn, lambda i, im: 100.0, lambda b, w, thresh, input_bits: [(k, 1, 2.0, 3.0) for k in range(len(b))],
+                         dict(graph_thresh_1=[5, 7]), rank, ws, log=lambda m: None)
+except distributed.RankFailed:
+    distributed.finish_process_group()
+    print("rank", rank, "failed cleanly", flush=True)
+    sys.exit(1)
+print("rank", rank, "unexpectedly succeeded")
+"""
+
+
+@pytest.mark.parametrize("nproc", [1, 2])
+def test_a_rank_that_cannot_load_an_image_fails_the_whole_run_without_a_hang(tmp_path, nproc):
+    """ADVICE (round 2): a rank that sys.exit()s inside its shard loop leaves the others blocked in the all-gather; the failure
+    now travels through the collective as a marker row and every rank exits with code 1"""
+    script = tmp_path / "failing.py"
+    script.write_text(FAILING.format(repo=str(REPO)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, str(script)] if nproc == 1 else [
+        sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+        "--master-port", str(port), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)       # a hang would hit the timeout
+    assert r.returncode != 0
+    assert r.stdout.count("failed cleanly") == nproc and "unexpectedly" not in r.stdout, r.stdout + r.stderr

@@ -213,7 +213,7 @@ def finish_distributed(ws: int):
 
 def run_stacks(args, config, paths, out_root: Path, rank: int, ws: int, local_rank: int):
     """Z-stack entries: the Sato branch (compute_branches.py:224-306) on this rank's share of the stacks"""
-    from tmat_amd import _lib, branches, helper, sato
+    from tmat_amd import _lib, branches, distributed, helper, sato
     if getattr(args, "detect_well", False):
         # compute_branches.py:231-243 makes the stack's well mask from a float64 anti-aliased resize of the max projection; that
         # input is not produced by this path yet (the 2-D branch and compute_cell_area.py accept -w)
@@ -230,7 +230,7 @@ def run_stacks(args, config, paths, out_root: Path, rank: int, ws: int, local_ra
             return load_stack(paths[img_id], args.channel, args.time)
         except (OSError, ValueError) as error:
             print(f"{FAIL}{error}", flush=True)
-            sys.exit(1)
+            raise branches.InputError(str(error))
 
     def width_fn(img_id, st):
         width_um = config.get("image_width_microns")
@@ -240,7 +240,7 @@ def run_stacks(args, config, paths, out_root: Path, rank: int, ws: int, local_ra
                 print(f"{FAIL} The --image-width-microns parameter was not specified, and the pixel to micron conversion "
                       f"factor was not found in the image metadata ({img_id}). Specify --image-width-microns and try again. "
                       "Exiting...", flush=True)
-                sys.exit(1)
+                raise branches.InputError(img_id)
             width_um = st.shape[-1] * px
         return width_um
 
@@ -265,7 +265,12 @@ def run_stacks(args, config, paths, out_root: Path, rank: int, ws: int, local_ra
         return st
 
     # one stack per analysis call (chunk=1): a stack is the unit the reference streams, and it can be gigabytes
-    gathered = branches.run_sharded(ids, load_and_keep, width_fn, analyze_fn, config, rank, ws, chunk=1, log=lambda m: print(m, flush=True))
+    try:
+        gathered = branches.run_sharded(ids, load_and_keep, width_fn, analyze_fn, config, rank, ws, chunk=1, log=lambda m: print(m, flush=True))
+    except distributed.RankFailed:
+        handle.close()
+        finish_distributed(ws)
+        sys.exit(1)
     write_results(args, config, ids, gathered, out_root, rank)
     handle.close()
     finish_distributed(ws)
@@ -340,7 +345,7 @@ def main(args=None):
             return load_image_2d(paths[img_id], args.channel, args.time)
         except (OSError, ValueError) as error:
             print(f"{FAIL}{error}", flush=True)
-            sys.exit(1)
+            raise branches.InputError(str(error))
 
     def width_fn(img_id, img):
         # image_width_microns: the option / config key, else per image from the file's metadata (reference
@@ -352,7 +357,7 @@ def main(args=None):
                 print(f"{FAIL} The --image-width-microns parameter was not specified, and the pixel to micron conversion "
                       f"factor was not found in the image metadata ({img_id}). Specify --image-width-microns and try again. "
                       "Exiting...", flush=True)
-                sys.exit(1)
+                raise branches.InputError(img_id)
             width_um = img.shape[-1] * px
         return width_um
 
@@ -378,8 +383,13 @@ def main(args=None):
             branches.save_visualizations(model.handle, img, out_root / "visualizations" / img_id, model.ds_ratio, 8 * img.dtype.itemsize)
         return img
 
-    gathered = branches.run_sharded(ids, load_and_keep, width_fn, analyze_fn, config, rank, ws,
-                                    log=lambda m: print(m, flush=True))
+    try:
+        gathered = branches.run_sharded(ids, load_and_keep, width_fn, analyze_fn, config, rank, ws,
+                                        log=lambda m: print(m, flush=True))
+    except distributed.RankFailed:          # the failing rank has printed the reference's message; every rank exits with code 1
+        model.handle.close()
+        finish_distributed(ws)
+        sys.exit(1)
     write_results(args, config, ids, gathered, out_root, rank)
     model.handle.close()
     finish_distributed(ws)

@@ -118,6 +118,7 @@ def main(argv=None):
             for (img_id, _), a, k in zip(items, area, kept):
                 areas[img_id], kept_all[img_id] = a, k
 
+    failed = False
     for i0 in range(0, len(mine), batch_size):
         group = {}
         for img_id in mine[i0:i0 + batch_size]:
@@ -128,9 +129,19 @@ def main(argv=None):
                     img = load_image_2d(paths[img_id], args.channel, args.time)
             except (OSError, ValueError) as error:
                 print(f"{FAIL}{error}", flush=True)
-                sys.exit(1)
+                failed = True               # still enter the gather below: the other ranks are waiting in it
+                break
             group.setdefault((img.shape, img.dtype.str), []).append((img_id, img))
+        if failed:
+            break
         flush(group)
+    index_of = {img_id: i for i, img_id in enumerate(img_ids)}
+    try:
+        gathered = distributed.gather_rows([] if failed else [(index_of[i], 0, areas[i], 0.0) for i in mine], n_total=len(img_ids), failed=failed)
+    except distributed.RankFailed:
+        handle.close()
+        distributed.finish_process_group()
+        sys.exit(1)
     print("... Areas computed successfully.", flush=True)
     print(OK, flush=True)
 
@@ -141,8 +152,6 @@ def main(argv=None):
             Image.fromarray(wells[img_id]).save(get_unique_output_filepath(out_root / THRESH_SUBDIR / f"{oid}_well_mask.png"))
         file = get_unique_output_filepath(out_root / THRESH_SUBDIR / f"{oid}_thresholded.png")
         Image.fromarray(kept_all[img_id]).save(file)
-    index_of = {img_id: i for i, img_id in enumerate(img_ids)}
-    gathered = distributed.gather_rows([(index_of[i], 0, areas[i], 0.0) for i in mine], n_total=len(img_ids))
     areas = {img_ids[g[0]]: g[2] for g in gathered}
     if rank != 0:
         handle.close()

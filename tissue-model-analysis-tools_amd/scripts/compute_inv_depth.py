@@ -141,7 +141,8 @@ def main(argv=None):
         sys.exit(1)
 
     rows = []
-    stack_ids = sorted(zstack_paths)              # a deterministic order the ranks agree on
+    failed = False
+    stack_ids = sorted(zstack_paths)              # a deterministic order the ranks agree on (the reference keeps glob order)
     for si in distributed.shard_indices(len(stack_ids), rank, ws):
         zstack_id = stack_ids[int(si)]
         zstack_path = zstack_paths[zstack_id]
@@ -153,14 +154,21 @@ def main(argv=None):
                 img, _ = helper.load_image(zstack_path, args.time, args.channel)
         except (OSError, ValueError) as error:
             print(f"{FAIL}{error}", flush=True)
-            sys.exit(1)
+            failed = True                         # still enter the gather below: the other ranks are waiting in it
+            break
         if img.ndim == 2:
             img = img[None]
         probs = ens.predict_stack(img)                              # (Z, n_pred_models): yhatp_m of compute_inv_depth.py:154
         for z, (inv_prob, inv_label) in enumerate(inv_depth.ensemble_predictions(probs, cls_thresh)):
             rows.append((int(si) * (1 << 20) + z, inv_label, float(inv_prob), 0.0))       # float32 -> float64 is exact; back below
 
-    rows = [(f"{stack_ids[r[0] >> 20]}_z{r[0] & ((1 << 20) - 1)}", np.float32(r[2]), r[1]) for r in distributed.gather_rows_ragged(rows)]
+    try:
+        gathered = distributed.gather_rows_ragged(rows, failed=failed)
+    except distributed.RankFailed:
+        handle.close()
+        distributed.finish_process_group()
+        sys.exit(1)
+    rows = [(f"{stack_ids[r[0] >> 20]}_z{r[0] & ((1 << 20) - 1)}", np.float32(r[2]), r[1]) for r in gathered]
     if rank != 0:
         handle.close()
         distributed.finish_process_group()

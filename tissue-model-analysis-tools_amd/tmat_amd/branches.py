@@ -124,6 +124,11 @@ def well_rows(handle: _lib.Handle, fields, config: dict, image_width_microns: fl
     return rows
 
 
+class InputError(Exception):
+    """an image of the run cannot be loaded / lacks its physical width: raised by run_sharded's callbacks (after they have
+    printed the reference's message); the run then fails on EVERY rank after the gather instead of leaving the others blocked"""
+
+
 def run_sharded(ids, load_fn, width_fn, analyze_fn, config: dict, rank: int = 0, world_size: int = 1, chunk: int = 64,
                 log=print):
     """The per-run driver of scripts/compute_branches.py (reference :585-594 loops over the images one by one):
@@ -149,19 +154,24 @@ def run_sharded(ids, load_fn, width_fn, analyze_fn, config: dict, rank: int = 0,
                     results[suffix].append((gidx, r[1], pixels_to_microns(r[2], DOWNSAMPLE_WIDTH, width_um),
                                             pixels_to_microns(r[3], DOWNSAMPLE_WIDTH, width_um)))
 
-    groups, held = {}, 0
+    groups, held, failed = {}, 0, False
     for gidx in mine:
         img_id = ids[int(gidx)]
         log(f"Analyzing {img_id}...")
-        img = load_fn(img_id)
-        width_um = width_fn(img_id, img)
+        try:
+            img = load_fn(img_id)
+            width_um = width_fn(img_id, img)
+        except InputError:
+            failed = True           # stop working, but still enter the collective below (distributed.gather_rows)
+            break
         groups.setdefault((img.shape, float(width_um), 8 * img.dtype.itemsize), []).append((int(gidx), img))
         held += 1
         if held >= chunk:           # bounded host / HBM footprint: the reference streams one image at a time
             flush(groups)
             groups, held = {}, 0
-    flush(groups)
-    return {suffix: distributed.gather_rows(results[suffix], n_total=len(ids)) for _, suffix in grid}
+    if not failed:
+        flush(groups)
+    return {suffix: distributed.gather_rows(results[suffix], n_total=len(ids), failed=failed) for _, suffix in grid}
 
 
 def save_visualizations(handle: _lib.Handle, img: np.ndarray, vis_dir, ds_ratio: float = 0.625, input_bits: int = 16):

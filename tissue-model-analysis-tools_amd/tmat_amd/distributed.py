@@ -33,19 +33,33 @@ def host_threads_per_rank(world_size: int) -> int:
     return max(1, min(ncpu // max(1, world_size), 32))
 
 
-def gather_rows(rows_local, n_total=None, device=None):
+class RankFailed(RuntimeError):
+    """some rank of the run could not process its shard (the message is printed on that rank)"""
+
+
+FAILED_INDEX = -2          # index of the marker row a failed rank contributes to the gather
+
+
+def gather_rows(rows_local, n_total=None, device=None, failed=False):
     """rows_local: list of (index, count, total_px, avg_px).  Returns the rows of ALL ranks sorted by index (on every
     rank) with ONE fixed-size all-gather: every rank pads its shard to ceil(n_total / world) rows of 32 bytes (the
     padding carries index -1).  `n_total` = number of rows over all ranks (the images of the run); when it is not
     given, a contiguous block partition of at most len(rows_local) + 1 rows per rank is assumed (shard_indices).
-    Single process: returns the input sorted."""
+    Single process: returns the input sorted.
+    `failed`: this rank could not finish its shard (an unreadable image, say).  It must still enter the collective -- a rank
+    that exits in front of it leaves the others blocked in the all-gather until the launcher kills them -- so it contributes
+    one marker row (index FAILED_INDEX) and EVERY rank raises RankFailed after the gather."""
     import torch
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if failed:
+            raise RankFailed("the run failed")
         return sorted(rows_local, key=lambda r: r[0])
     ws = dist.get_world_size()
-    cap = -(-int(n_total) // ws) if n_total is not None else len(rows_local) + 1
+    cap = max(1, -(-int(n_total) // ws) if n_total is not None else len(rows_local) + 1)
+    if failed:
+        rows_local = [(FAILED_INDEX, 0, 0.0, 0.0)]
     if len(rows_local) > cap:
         raise ValueError(f"gather_rows: {len(rows_local)} local rows exceed the shard capacity {cap}")
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -57,6 +71,8 @@ def gather_rows(rows_local, n_total=None, device=None):
     out = torch.empty(ws * cap * ROW_DTYPE.itemsize, dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(out, inp)           # the one collective of the path (RCCL over xGMI on GPUs)
     allrows = out.cpu().numpy().view(ROW_DTYPE)
+    if (allrows["index"] == FAILED_INDEX).any():
+        raise RankFailed("a rank of the run failed")
     allrows = allrows[allrows["index"] >= 0]
     return sorted(((int(r["index"]), int(r["count"]), float(r["total"]), float(r["avg"])) for r in allrows), key=lambda r: r[0])
 
@@ -83,14 +99,16 @@ def finish_process_group():
         dist.destroy_process_group()
 
 
-def gather_rows_ragged(rows_local, device=None):
+def gather_rows_ragged(rows_local, device=None, failed=False):
     """gather_rows for shards whose row counts are not known up front (the invasion-depth tool: one row per Z slice, stacks of
     different depth): an all-reduce(max) of the local counts fixes the shard capacity, then the one all-gather"""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if failed:
+            raise RankFailed("the run failed")
         return sorted(rows_local, key=lambda r: r[0])
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-    cap = torch.tensor([len(rows_local)], dtype=torch.int64, device=dev)
+    cap = torch.tensor([max(1, len(rows_local))], dtype=torch.int64, device=dev)
     dist.all_reduce(cap, op=dist.ReduceOp.MAX)
-    return gather_rows(rows_local, n_total=int(cap.item()) * dist.get_world_size(), device=device)
+    return gather_rows(rows_local, n_total=int(cap.item()) * dist.get_world_size(), device=device, failed=failed)
