@@ -67,3 +67,41 @@ def test_full_size_field_device_equals_host(plain):
     V0, E0 = _lib.dmt_graph(f, 5.0, 10.0)
     V1, E1 = _lib.dmt_graph(f, 5.0, 10.0, handle=plain)
     assert len(V0) > 100 and np.array_equal(V0, V1) and np.array_equal(E0, E1)
+
+
+def test_device_sweeps_match_reference_goldens_and_timing():
+    """TMAT_DMT_SWEEP_DEVICE=1: the two persistence sweeps (dmtgraph.py:277-314) as a one-wave-per-image kernel
+    (csrc/dmt_sweep_kernels.hip), `collect` on the host: all 27 golden cases exact.  Runs in a child process (the switch is
+    read once per process) and prints the time of the 384 x 384 case next to the host sweeps' -- the kernel is NOT the
+    default: it is slower than the host threads it would replace."""
+    import os, subprocess, sys
+    code = r'''
+import sys, time
+sys.path[:0] = [r"%(repo)s", r"%(repo)s/tissue-model-analysis-tools_amd", r"%(repo)s/tools", r"%(repo)s/tests"]
+import numpy as np
+from test_gpu_dmt import FIELDS, GD, DELTAS
+from make_goldens import synth_field
+from tmat_amd import _lib
+h = _lib.Handle(None, 0)
+for name in sorted(FIELDS):
+    for deltas in DELTAS:
+        V, E = _lib.dmt_graph(FIELDS[name], *deltas, handle=h)
+        key = f"{name}_{deltas[0]}_{deltas[1]}"
+        assert np.array_equal(V, GD[key + "_V"].reshape(-1, 2)) and np.array_equal(E, GD[key + "_E"].reshape(-1, 2)), key
+f = synth_field(77, (384, 384))
+_lib.dmt_graph(f, 5.0, 10.0, handle=h)
+t0 = time.perf_counter()
+for _ in range(3):
+    V1, E1 = _lib.dmt_graph(f, 5.0, 10.0, handle=h)
+print("ms_per_384_field", (time.perf_counter() - t0) / 3 * 1e3, len(V1), len(E1))
+h.close()
+'''
+    repo = str(Path(__file__).resolve().parents[1])
+    out = {}
+    for dev in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code % dict(repo=repo)], env=dict(os.environ, TMAT_DMT_SWEEP_DEVICE=dev), capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out[dev] = r.stdout.strip().splitlines()[-1].split()
+    assert out["1"][2:] == out["0"][2:]
+    print(f"\ntmat_dmt_graph on one 384 x 384 field, whole call: device sweeps {float(out['1'][1]):.1f} ms, host sweeps {float(out['0'][1]):.1f} ms")

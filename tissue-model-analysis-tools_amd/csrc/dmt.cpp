@@ -100,8 +100,9 @@ static void sorted_edges_host(const float *val, const Grid &gd, std::vector<int3
 
 // `sorted` / m: the kept edges in lower-star order when the device front end (csrc/dmt_kernels.hip) produced them; NULL =
 // filter and sort here
+// kind_in / pers_in (nullable, m_in entries): the result of the two sweeps when the device ran them (dmt_sweep_kernels.hip)
 int dmt_graph_host_sorted(const float *img, int R, int C, float delta1, float delta2, const int32_t *sorted, int m_in, int32_t *verts,
-                          int cap_v, int32_t *edges, int cap_e, int *n_verts, int *n_edges)
+                          int cap_v, int32_t *edges, int cap_e, int *n_verts, int *n_edges, const uint8_t *kind_in, const float *pers_in)
 {
     *n_verts = 0; *n_edges = 0;
     if (R < 1 || C < 1) { set_error("tmat_dmt_graph: empty image"); return TMAT_E_ARG; }
@@ -121,6 +122,9 @@ int dmt_graph_host_sorted(const float *img, int R, int C, float delta1, float de
         int a, b; gd.endpoints(se[i], a, b);
         ea[i] = a; eb[i] = b; ev[i] = val[a] > val[b] ? val[a] : val[b];
     }
+    if (kind_in && pers_in) {
+        for (int i = 0; i < m; i++) { kind[i] = kind_in[i]; pers[i] = pers_in[i]; }
+    } else {
     // ---- ascending sweep: elder rule on vertices (younger = larger value, ties by larger index, dies) ----
     {
         std::vector<int32_t> p(nV);
@@ -159,6 +163,7 @@ int dmt_graph_host_sorted(const float *img, int R, int C, float delta1, float de
             pers[i] = tv[dead] - ev[i];
             kind[i] = 2;
         }
+    }
     }
     // ---- collect: low-persistence tree edges, at most 4 links per vertex, in descending edge order ----
     std::vector<int32_t> link(4 * (size_t)nV, -1);
@@ -228,7 +233,7 @@ int dmt_graph_host_sorted(const float *img, int R, int C, float delta1, float de
 int dmt_graph_host(const float *img, int R, int C, float delta1, float delta2, int32_t *verts, int cap_v, int32_t *edges,
                    int cap_e, int *n_verts, int *n_edges)
 {
-    return dmt_graph_host_sorted(img, R, C, delta1, delta2, nullptr, 0, verts, cap_v, edges, cap_e, n_verts, n_edges);
+    return dmt_graph_host_sorted(img, R, C, delta1, delta2, nullptr, 0, verts, cap_v, edges, cap_e, n_verts, n_edges, nullptr, nullptr);
 }
 
 }  // namespace tmat

@@ -352,12 +352,26 @@ int dmt_graph_device_front(void *handle, const float *img, int R, int C, float d
         !hip_ok(hipMalloc((void **)&ids, nE * sizeof(int32_t)), "hipMalloc") || !hip_ok(hipMalloc((void **)&m, sizeof(int)), "hipMalloc")) rc = TMAT_E_HIP;
     if (!rc && !hip_ok(hipMemcpyAsync(df, img, npx * sizeof(float), hipMemcpyHostToDevice, c->stream), "H2D")) rc = TMAT_E_HIP;
     if (!rc && dmt_sorted_edges_dev(df, 1, R, C, ws, ids, m, c->stream)) { set_error("tmat_dmt_graph: device front end failed"); rc = TMAT_E_HIP; }
+    // opt-in: the two persistence sweeps on the device too (dmt_sweep_kernels.hip, one wave per image); `collect` stays on the host
+    static const bool sweep_dev = [] { const char *e = getenv("TMAT_DMT_SWEEP_DEVICE"); return e && atoi(e) != 0; }();
+    std::vector<uint8_t> kind_host;
+    std::vector<float> pers_host;
+    void *sws = nullptr; uint8_t *dkind = nullptr; float *dpers = nullptr;
+    if (!rc && sweep_dev) {
+        kind_host.resize(nE); pers_host.resize(nE);
+        if (!hip_ok(hipMalloc(&sws, dmt_sweep_workspace_bytes(1, R, C)), "hipMalloc") || !hip_ok(hipMalloc((void **)&dkind, nE), "hipMalloc") ||
+            !hip_ok(hipMalloc((void **)&dpers, nE * sizeof(float)), "hipMalloc")) rc = TMAT_E_HIP;
+        if (!rc && dmt_sweeps_dev(df, ids, m, 1, R, C, sws, dkind, dpers, c->stream)) { set_error("tmat_dmt_graph: device sweeps failed"); rc = TMAT_E_HIP; }
+        if (!rc && (!hip_ok(hipMemcpyAsync(kind_host.data(), dkind, nE, hipMemcpyDeviceToHost, c->stream), "D2H") ||
+                    !hip_ok(hipMemcpyAsync(pers_host.data(), dpers, nE * sizeof(float), hipMemcpyDeviceToHost, c->stream), "D2H"))) rc = TMAT_E_HIP;
+    }
     if (!rc && (!hip_ok(hipMemcpyAsync(ids_host.data(), ids, nE * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream), "D2H") ||
-                !hip_ok(hipMemcpyAsync(&m_host, m, sizeof(int), hipMemcpyDeviceToHost, c->stream), "D2H") ||
-                !hip_ok(hipStreamSynchronize(c->stream), "sync"))) rc = TMAT_E_HIP;
-    hipFree(df); hipFree(ws); hipFree(ids); hipFree(m);
+                !hip_ok(hipMemcpyAsync(&m_host, m, sizeof(int), hipMemcpyDeviceToHost, c->stream), "D2H"))) rc = TMAT_E_HIP;
+    if (!hip_ok(hipStreamSynchronize(c->stream), "sync") && !rc) rc = TMAT_E_HIP;
+    hipFree(df); hipFree(ws); hipFree(ids); hipFree(m); hipFree(sws); hipFree(dkind); hipFree(dpers);
     if (rc) return rc;
-    return dmt_graph_host_sorted(img, R, C, delta1, delta2, ids_host.data(), m_host, verts, cap_v, edges, cap_e, n_verts, n_edges);
+    return dmt_graph_host_sorted(img, R, C, delta1, delta2, ids_host.data(), m_host, verts, cap_v, edges, cap_e, n_verts, n_edges,
+                                 sweep_dev ? kind_host.data() : nullptr, sweep_dev ? pers_host.data() : nullptr);
 }
 
 }  // namespace tmat
