@@ -379,24 +379,20 @@ int tmat_zproj_dev(tmat_handle h, const uint16_t *stacks_dev, int n, int Z, int 
  * Arithmetic of the dense convolutions of the UNet (reference: keras Model.predict in float32, models.py:615-622, 644).
  *   TMAT_PRECISION_F32    (default) f32 operands on v_mfma_f32_32x32x2_f32: bit-exact with oracle/unet_exact.c.
  *   TMAT_PRECISION_BF16X3 opt-in split precision: every f32 operand as a bf16 hi + bf16 lo pair, three bf16 MFMAs per
- *                         product (lo*hi + hi*lo + hi*hi) with f32 accumulation; about 2^-16 relative error per product,
- *                         NOT bit-exact; gated by the north-star tolerance (branch counts equal, lengths within 1e-4) in
- *                         tests/test_gpu_alt_precision.py and reported by bench.py as a separate "alt" block.  Applies to the
- *                         3x3 / sub-pixel / 1x1 convolutions of conv_mfma_kernel; the fused separable convolutions, stem and
- *                         final layer stay f32.
+ *                         product (lo*hi + hi*lo + hi*hi) with f32 accumulation; about 2^-16 relative error per product.
+ *   TMAT_PRECISION_BF16X6 opt-in: hi + mid + lo (the whole 24-bit mantissa), the six products of order <= 2 (lo*hi, hi*lo,
+ *                         mid*mid, mid*hi, hi*mid, hi*hi): 2^-24-level error, i.e. f32-equivalent results at 3/8 of the
+ *                         f32 path's matrix-pipe time.
+ *   Neither opt-in mode is bit-exact with the oracle; both are gated by the north-star tolerance (branch counts equal,
+ *   lengths within 1e-4) in tests/test_gpu_alt_precision.py and reported by bench.py as a separate "alt" block.  They apply
+ *   to the 3x3 / sub-pixel / 1x1 convolutions of conv_mfma_kernel; the fused separable convolutions, stem and final layer
+ *   stay f32.
  * Takes effect for the calls that follow (the handle's streams are drained first).  The environment variable
- * TMAT_PRECISION=f32|bf16x3 selects the mode at tmat_create.
+ * TMAT_PRECISION=f32|bf16x3|bf16x6 selects the mode at tmat_create.
  */
-/*
- * UNetXceptionPatchSegmentor's optional input normalisation, x = (x - norm_mean) / norm_std in float32 (reference
- * models.py:600-612, 636-637; keys norm_mean / norm_std of the model config), applied on the device in front of
- * predict_img_with_smooth_windowing by every entry point that runs it (tmat_predict_smooth, tmat_segment_batch,
- * tmat_analyze_batch*).  Off by default (the shipped unet_patch_segmentor_1.json has no such keys).
- */
-int tmat_set_input_norm(tmat_handle h, int on, double norm_mean, double norm_std);
-
 #define TMAT_PRECISION_F32 0
 #define TMAT_PRECISION_BF16X3 1
+#define TMAT_PRECISION_BF16X6 2
 int tmat_set_precision(tmat_handle h, int mode);
 
 /*

@@ -190,7 +190,10 @@ static int resnet_forward_dev(const ResNetModel &m, const float *x, int N, int S
 {
     float *a = bufs[0], *b = bufs[1], *t1 = bufs[2], *t2 = bufs[3];
     const int S2 = S / 2, S4 = S / 4;
-    hipLaunchKernelGGL(resnet_stem_kernel, dim3(std::min(S2 * S2 / 4, 4096), N), dim3(256), 0, s, x, S, m.stem_w, m.stem_scale, m.stem_shift, a);
+    // every workgroup first copies the 37 KB of stem weights to LDS: give it enough pixels to pay for that (round 2 launched
+    // one workgroup per 4 output pixels, i.e. 37 KB of LDS fill per 256 outputs; the grid-stride loop was never taken)
+    const int stem_blocks = std::max(1, std::min(S2 * S2 / 4, std::max(8, 2048 / std::max(N, 1))));
+    hipLaunchKernelGGL(resnet_stem_kernel, dim3(stem_blocks, N), dim3(256), 0, s, x, S, m.stem_w, m.stem_scale, m.stem_shift, a);
     const size_t ptotal = (size_t)N * S4 * S4 * 64;
     hipLaunchKernelGGL(resnet_pool_kernel, dim3((unsigned)std::min<size_t>((ptotal + 255) / 256, 16384)), dim3(256), 0, s, a, S2, 64, b, ptotal);
     float *cur = b, *nxt = a;
@@ -311,7 +314,7 @@ int tmat_inv_depth_predict(tmat_handle hd, const int *model_ids, int n_models, c
     if (Z == 0) return TMAT_OK;
     TMAT_HIP(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    const int CH = 32;                                     // slices per forward
+    const int CH = 128;                                    // slices per forward: M = 128 x 16^2 rows at the deepest stage (round 2: 32, launch bound)
     const size_t npx = (size_t)size * size;
     uint16_t *din = nullptr, *dsm = nullptr;
     int *itab = nullptr, *mnmx = nullptr;

@@ -89,24 +89,22 @@ static float bf16_to_f32(uint16_t b)
     memcpy(&x, &u, 4);
     return x;
 }
-// Split-precision copy of conv weights for conv_mfma_kernel<..., PREC = 1> (unet_kernels.hip): rows of Cin f32 values become
-// rows of the same byte length in which every 128-byte block of 32 input channels holds 32 bf16 hi = rne(w) followed by 32
-// bf16 lo = rne(w - hi).
-static std::vector<float> split_bf16(const std::vector<float> &w, int cin)
+// Split-precision copy of conv weights for conv_mfma_kernel<..., PREC = 1 | 2> (unet_kernels.hip): npl bf16 planes of the
+// tensor's own layout, plane 0 = rne(w), plane 1 = rne(w - p0), plane 2 = rne(w - p0 - p1) (each difference is exact in f32).
+// Returned as a float vector used as a byte container (npl * w.size() bf16 values).
+static std::vector<float> split_bf16(const std::vector<float> &w, int npl)
 {
-    std::vector<float> out(w.size());
+    std::vector<float> out((w.size() * npl + 1) / 2);
     uint16_t *o = reinterpret_cast<uint16_t *>(out.data());
-    const size_t rows = w.size() / cin;
-    for (size_t r = 0; r < rows; r++)
-        for (int cb = 0; cb < cin / 32; cb++) {
-            const float *src = &w[r * cin + cb * 32];
-            uint16_t *dst = o + (r * cin + cb * 32) * 2;
-            for (int k = 0; k < 32; k++) {
-                const uint16_t hi = bf16_rne(src[k]);
-                dst[k] = hi;
-                dst[32 + k] = bf16_rne(src[k] - bf16_to_f32(hi));
-            }
+    const size_t n = w.size();
+    for (size_t i = 0; i < n; i++) {
+        float rem = w[i];
+        for (int pl = 0; pl < npl; pl++) {
+            const uint16_t q = bf16_rne(rem);
+            o[(size_t)pl * n + i] = q;
+            rem = rem - bf16_to_f32(q);
         }
+    }
     return out;
 }
 
@@ -303,9 +301,10 @@ static bool conv(Ctx *c, ConvArgs a, hipStream_t st)
         double H = (double)a.h, W = (double)a.w;
         prof_begin(c, 2.0 * a.N * H * W * 9.0 * a.Cin * a.Cout, st);
     }
-    if (c->precision == 1) {        // opt-in split precision: the same launch on the split copy of the weights
-        auto it = c->wsplit.find(a.W);
-        if (it != c->wsplit.end()) { a.W = it->second; a.prec = 1; }
+    if (c->precision != TMAT_PRECISION_F32) {        // opt-in split precision: the same launch on the split copy of the weights
+        auto &mp = c->wsplit[c->precision];
+        auto it = mp.find(a.W);
+        if (it != mp.end()) { a.W = it->second; a.prec = c->precision; }
     }
     bool ok = launch_conv(a, st);
     if (dom) prof_end(c, st);
@@ -529,8 +528,8 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
     if (const char *e = getenv("TMAT_FUSED_POOL")) c->fused_pool = atoi(e) != 0;
     if (const char *e = getenv("TMAT_SEP_WS")) c->sep_ws = atoi(e) != 0;
     const char *prec_env = getenv("TMAT_PRECISION");
-    if (prec_env && strcmp(prec_env, "f32") && strcmp(prec_env, "bf16x3")) {
-        set_error("tmat_create: TMAT_PRECISION must be f32 or bf16x3");
+    if (prec_env && strcmp(prec_env, "f32") && strcmp(prec_env, "bf16x3") && strcmp(prec_env, "bf16x6")) {
+        set_error("tmat_create: TMAT_PRECISION must be f32, bf16x3 or bf16x6");
         delete c;
         return TMAT_E_ARG;
     }
@@ -599,8 +598,8 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
         c->win_host = wind;
     }
     *out = (tmat_handle)c;
-    if (prec_env && !strcmp(prec_env, "bf16x3")) {
-        const int rc = tmat_set_precision((tmat_handle)c, TMAT_PRECISION_BF16X3);
+    if (prec_env && strcmp(prec_env, "f32")) {
+        const int rc = tmat_set_precision((tmat_handle)c, !strcmp(prec_env, "bf16x3") ? TMAT_PRECISION_BF16X3 : TMAT_PRECISION_BF16X6);
         if (rc) { tmat_destroy((tmat_handle)c); *out = nullptr; return rc; }
     }
     return TMAT_OK;
@@ -728,17 +727,18 @@ int tmat_set_input_norm(tmat_handle h, int on, double mean, double sd)
 int tmat_set_precision(tmat_handle h, int mode)
 {
     Ctx *c = (Ctx *)h;
-    if (!c || !has_model(c) || (mode != TMAT_PRECISION_F32 && mode != TMAT_PRECISION_BF16X3)) {
-        set_error("tmat_set_precision: needs a model handle and mode TMAT_PRECISION_F32 or TMAT_PRECISION_BF16X3");
+    if (!c || !has_model(c) || (mode != TMAT_PRECISION_F32 && mode != TMAT_PRECISION_BF16X3 && mode != TMAT_PRECISION_BF16X6)) {
+        set_error("tmat_set_precision: needs a model handle and mode TMAT_PRECISION_F32, TMAT_PRECISION_BF16X3 or TMAT_PRECISION_BF16X6");
         return TMAT_E_ARG;
     }
     TMAT_HIP(hipSetDevice(c->device));
-    if (mode == TMAT_PRECISION_BF16X3) {
+    if (mode != TMAT_PRECISION_F32) {
+        auto &mp = c->wsplit[mode];
         for (auto &kv : c->conv_w_host) {
-            if (c->wsplit.count(kv.first)) continue;
+            if (mp.count(kv.first)) continue;
             float *dev = nullptr;
-            if (!upload(c, split_bf16(kv.second.w, kv.second.cin), &dev)) return TMAT_E_HIP;
-            c->wsplit[kv.first] = dev;
+            if (!upload(c, split_bf16(kv.second.w, mode + 1), &dev)) return TMAT_E_HIP;
+            mp[kv.first] = dev;
         }
     }
     TMAT_HIP(hipStreamSynchronize(c->stream));

@@ -143,9 +143,9 @@ struct Ctx {
     bool fused_pool = true;                                  // max-pool + residual add fused behind the second separable convolution (TMAT_FUSED_POOL=0: separate kernel)
     bool norm_on = false;                                    // models.py:636-637 input normalisation in front of the smooth prediction (tmat_set_input_norm)
     float norm_mean = 0.f, norm_std = 1.f;
-    int precision = 0;                                       // TMAT_PRECISION_F32 (bit-exact contract) or TMAT_PRECISION_BF16X3 (opt-in, tmat_set_precision)
+    int precision = 0;                                       // TMAT_PRECISION_F32 (bit-exact contract) or TMAT_PRECISION_BF16X3 / _BF16X6 (opt-in, tmat_set_precision)
     std::map<const float *, ConvWHost> conv_w_host;          // device pointer of every MFMA convolution weight tensor -> its host copy
-    std::map<const float *, float *> wsplit;                 // ... -> its split-precision copy on the device (made on first use)
+    std::map<int, std::map<const float *, float *>> wsplit;  // precision mode -> (... -> its split-precision copy on the device, made on first use)
     bool sep_ws = true;                                      // wave-specialised form of the fused separable kernel (TMAT_SEP_WS=0: sepconv_mfma_kernel)
     bool fused_sep = true;                                   // fused depthwise->pointwise kernel where the level allows (TMAT_FUSED_SEP=0: off)
     // profiling of the dominant kernel family

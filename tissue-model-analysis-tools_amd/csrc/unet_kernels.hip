@@ -42,15 +42,18 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // PREC = 0: f32 operands on v_mfma_f32_32x32x2_f32 (the bit-exact path, everything above).
-// PREC = 1: "bf16x3" split precision (opt-in, tmat_set_precision): every f32 operand x is split into bf16 hi = rne(x) and
-//   lo = rne(x - hi), and a product a w is taken as a_lo w_hi + a_hi w_lo + a_hi w_hi on v_mfma_f32_32x32x16_bf16 with f32
-//   accumulation (three bf16 MFMAs do the work of eight f32 ones at 1/2 the cycles each: 5.3x less matrix time per MAC).
-//   The dropped term and the two roundings leave a relative error of about 2^-16 per product -- not bit-exact with the
-//   oracle; tests/test_gpu_alt_precision.py gates it by the tolerance of BASELINE.json's north_star (counts equal, lengths
-//   within 1e-4) and bench.py reports it as a separate "alt" block.  Activations stay f32 in HBM and in LDS and are split
-//   in registers after the fragment read (the vector ALU and the bf16 matrix pipe run side by side); the WEIGHTS are split
-//   once on the host (tmat_api.cpp:split_bf16): a 128-byte LDS row of 32 input channels holds 32 bf16 hi values then 32 bf16
-//   lo values, so the LDS-DMA addressing, the swizzle and the tile geometry are those of the f32 path unchanged.
+// PREC = 1, 2: split precision on the bf16 matrix cores, opt-in (tmat_set_precision), f32 accumulation:
+//   1 "bf16x3": x = hi + lo (hi = rne_bf16(x), lo = rne_bf16(x - hi)); a w ~ a_lo w_hi + a_hi w_lo + a_hi w_hi: three
+//     v_mfma_f32_32x32x16_bf16 do the work of eight f32 MFMAs at half the cycles each.  About 2^-16 relative error per product.
+//   2 "bf16x6": x = hi + mid + lo (24 bits: the whole f32 mantissa); the six products of total order <= 2
+//     (lo hi, hi lo, mid mid, mid hi, hi mid, hi hi): dropped terms are 2^-24 relative, i.e. f32-level error, at 3/8 of the
+//     matrix-pipe time of the f32 path.
+//   Neither is bit-exact with the oracle: tests/test_gpu_alt_precision.py gates them by the tolerance of BASELINE.json's
+//   north_star (counts equal, lengths within 1e-4) and bench.py reports them as a separate "alt" block.
+//   Activations stay f32 in HBM and in LDS and are split in registers after the fragment read (the vector ALU and the bf16
+//   matrix pipe run side by side, unlike the f32 MFMA).  The WEIGHTS are split once on the host (tmat_api.cpp:split_bf16)
+//   into NPL = 2 / 3 bf16 PLANES [plane][tap][Cout][Cin]; a stage holds the A rows as in the f32 path and NPL weight planes
+//   of [BN rows][32 bf16] (64-byte rows, 16-byte unit u of row r in slot u ^ ((r >> 2) & 3): conflict-free ds_read_b128).
 template <int BM, int BN, int WM, int WN, int KS, bool RELU, int PREC = 0>
 #ifndef TMAT_CONV_WPS
 #define TMAT_CONV_WPS 4     // waves per SIMD the 8-wave conv kernel is compiled for (VGPR budget 512 / this)
@@ -69,7 +72,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
     constexpr int KC = 32;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int NPA = BM / RP, NPB = BN / RP;      // DMA passes
-    constexpr int STAGE = (BM + BN) * KC;            // floats per stage: A rows, then B rows
+    constexpr int NPL = PREC == 0 ? 0 : PREC + 1;                            // bf16 weight planes of the split-precision forms
+    constexpr int NPLA = NPL > 0 ? NPL : 1;                                  // array extent (the f32 instantiation never runs that code)
+    constexpr int STAGE = PREC == 0 ? (BM + BN) * KC : BM * KC + NPL * BN * 16;   // floats per stage: A rows, then B rows / B planes
     constexpr int EPR = 128 * BN <= STAGE ? 128 : 64;   // rows of the epilogue staging tile (it reuses stage 0)
     static_assert(EPR * BN <= STAGE, "epilogue tile fits one stage");
     static_assert(NPA >= 1 && NPA <= 8 && NPA * RP == BM, "A passes");
@@ -156,9 +161,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
     const __amdgpu_buffer_rsrc_t rsA =
         __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + ((long)p0 - a.w - 1) * a.Cin), 0, 0x7fffffff, 0x00020000);
     // weights [tap][Cout][Cin] (KS == 2: [class][tap][Cout][Cin]): row n0 + pass * RP + srow, this lane's channel group
+    const size_t wofs = (KS == 2 ? (size_t)blockIdx.y * 4 * a.Cin * a.Cout : (size_t)0) + (size_t)n0 * a.Cin;      // elements
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(a.W + (KS == 2 ? (size_t)blockIdx.y * 4 * a.Cin * a.Cout : (size_t)0) + (size_t)n0 * a.Cin), 0, 0x7fffffff, 0x00020000);
+        PREC == 0 ? (void *)(a.W + wofs) : (void *)((const char *)a.W + wofs * 2), 0, 0x7fffffff, 0x00020000);
     const unsigned wv = (unsigned)(srow * a.Cin + c4) * 4u;
+    // split-precision planes: lane t loads the 16-byte unit ((t & 3) ^ ((row >> 2) & 3)) of row t >> 2 (64 bytes of bf16 per row and chunk);
+    // the buffer base of a plane row is in bf16 elements what rsB's is in floats, so the same descriptor serves with halved offsets
+    const unsigned wvp = (unsigned)((t >> 2) * a.Cin * 2 + (((t & 3) ^ ((t >> 4) & 3)) * 16));
+    const int plane_bytes = (KS == 2 ? 16 : taps) * a.Cout * a.Cin * 2;
     const int wtap = a.Cout * a.Cin * 4;             // bytes per tap
     const int wpass = RP * a.Cin * 4;                // bytes per DMA pass of weight rows
     const int ldsw = wave * 8 * KC;                  // this wave's 8 rows (1 KiB) inside an RP-row pass
@@ -170,8 +180,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t *)(st + i * RP * KC + ldsw), 16, vo, soA, 0, 0); \
     }
 #define TMAT_DMA_B(i)                                                                                        \
-    if (i < NPB)                                                                                             \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t *)(st + (BM + i * RP) * KC + ldsw), 16, wv, soB + i * wpass, 0, 0);
+    if (PREC == 0 && i < NPB)                                                                                \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t *)(st + (BM + i * RP) * KC + ldsw), 16, wv, soB + i * wpass, 0, 0); \
+    if (PREC != 0 && i < NPL && wave * 16 < BN)      /* plane i: this wave's 16 rows of 64 bytes */          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t *)(st + BM * KC + i * BN * 16 + wave * 256), 16, wvp, soBp + i * plane_bytes, 0, 0);
 #define TMAT_ISSUE_CHUNK(stage_)                                                       \
     {                                                                                  \
         float *st = (stage_);                                                          \
@@ -179,6 +191,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
         const int dx = KS == 3 ? ld_tap % 3 - 1 : KS == 2 ? spx - 1 + (ld_tap & 1) : 0;  \
         const int soA = (((dy + 1) * a.w + dx + 1) * a.Cin + ld_cb * KC) * 4;          \
         const int soB = ld_tap * wtap + ld_cb * KC * 4;                                \
+        const int soBp = ld_tap * (wtap >> 1) + ld_cb * KC * 2;      /* bf16 planes */     \
         const unsigned tbit = 1u << ld_tap;                                            \
         TMAT_DMA_A(0) TMAT_DMA_A(1) TMAT_DMA_A(2) TMAT_DMA_A(3)                        \
         TMAT_DMA_A(4) TMAT_DMA_A(5) TMAT_DMA_A(6) TMAT_DMA_A(7)                        \
@@ -279,44 +292,60 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
     }
 #endif
 
-    // bf16x3 step: k step t (t = 0, 1) of the chunk covers channels 16t .. 16t+15; a lane's 8 values are channels
-    // 16t + 8h + j (A: 16-byte units 4t+2h, 4t+2h+1 of its f32 row; B: unit 2t+h = hi, unit 4+2t+h = lo of its split row)
+    // split-precision step: k step tk (0, 1) of the chunk covers channels 16 tk .. 16 tk + 15; a lane's 8 values are channels
+    // 16 tk + 8 h + j (A: 16-byte units 4 tk + 2 h, 4 tk + 2 h + 1 of its f32 row; B: unit 2 tk + h of its row in every plane)
+    const int browp = BM * KC + (wn * (BN / WN) + (lane & 31)) * 16;
+    const int keyb = (lane >> 2) & 3;
 #define TMAT_STEP_BF16(cur, nxt, more)                                                 \
     {                                                                                  \
         float4 af[2][TM][2];                                                           \
-        bf16x8 bh[2][TN], bl[2][TN];                                                   \
         _Pragma("unroll") for (int tk = 0; tk < 2; tk++) {                             \
             const int sa = ((4 * tk + 2 * hi) ^ key) * 4, sb = ((4 * tk + 2 * hi + 1) ^ key) * 4; \
-            const int sh = ((2 * tk + hi) ^ key) * 4, sl = ((4 + 2 * tk + hi) ^ key) * 4; \
             _Pragma("unroll") for (int i = 0; i < TM; i++) {                           \
                 af[tk][i][0] = *reinterpret_cast<const float4 *>((cur) + arow + i * 32 * KC + sa); \
                 af[tk][i][1] = *reinterpret_cast<const float4 *>((cur) + arow + i * 32 * KC + sb); \
             }                                                                          \
-            _Pragma("unroll") for (int jn = 0; jn < TN; jn++) {                        \
-                bh[tk][jn] = *reinterpret_cast<const bf16x8 *>((cur) + brow + jn * 32 * KC + sh); \
-                bl[tk][jn] = *reinterpret_cast<const bf16x8 *>((cur) + brow + jn * 32 * KC + sl); \
-            }                                                                          \
         }                                                                              \
+        bf16x8 bp[2][NPLA][TN];                                                        \
+        /* three planes: the second k step's weight fragments are read behind the first one's MFMAs (128-VGPR budget) */ \
+        _Pragma("unroll") for (int tk = 0; tk < (NPL == 3 ? 1 : 2); tk++)              \
+            _Pragma("unroll") for (int pl = 0; pl < NPL; pl++)                         \
+                _Pragma("unroll") for (int jn = 0; jn < TN; jn++)                      \
+                    bp[tk][pl][jn] = *reinterpret_cast<const bf16x8 *>((cur) + browp + pl * BN * 16 + jn * 32 * 16 + (((2 * tk + hi) ^ keyb) * 4)); \
         TMAT_PIN()                                                                     \
         if (more) TMAT_LOOP_ISSUE(nxt)                                                 \
         TMAT_PIN()                                                                     \
         _Pragma("unroll") for (int tk = 0; tk < 2; tk++) {                             \
-            bf16x8 ah[TM], al[TM];                                                     \
+            if (NPL == 3 && tk == 1) {                                                 \
+                _Pragma("unroll") for (int pl = 0; pl < NPL; pl++)                     \
+                    _Pragma("unroll") for (int jn = 0; jn < TN; jn++)                  \
+                        bp[1][pl][jn] = *reinterpret_cast<const bf16x8 *>((cur) + browp + pl * BN * 16 + jn * 32 * 16 + (((2 + hi) ^ keyb) * 4)); \
+            }                                                                          \
+            bf16x8 ap[NPLA][TM];                                                       \
             _Pragma("unroll") for (int i = 0; i < TM; i++) {                           \
                 float xs[8] = {af[tk][i][0].x, af[tk][i][0].y, af[tk][i][0].z, af[tk][i][0].w, \
                                af[tk][i][1].x, af[tk][i][1].y, af[tk][i][1].z, af[tk][i][1].w}; \
                 _Pragma("unroll") for (int j = 0; j < 8; j++) {                        \
-                    if (RELU) xs[j] = TMAT_RELU(xs[j]);                                \
-                    const __bf16 hb = (__bf16)xs[j];                                   \
-                    ah[i][j] = hb;                                                     \
-                    al[i][j] = (__bf16)(xs[j] - (float)hb);                            \
+                    float rem = RELU ? TMAT_RELU(xs[j]) : xs[j];                       \
+                    _Pragma("unroll") for (int pl = 0; pl < NPL; pl++) {               \
+                        const __bf16 q = (__bf16)rem;                                  \
+                        ap[pl][i][j] = q;                                              \
+                        rem = rem - (float)q;                                          \
+                    }                                                                  \
                 }                                                                      \
             }                                                                          \
             _Pragma("unroll") for (int i = 0; i < TM; i++)                             \
                 _Pragma("unroll") for (int jn = 0; jn < TN; jn++) {                    \
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[tk][jn], acc[i][jn], 0, 0, 0); \
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[tk][jn], acc[i][jn], 0, 0, 0); \
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[tk][jn], acc[i][jn], 0, 0, 0); \
+                    /* smallest products first; NPL == 2: lo hi, hi lo, hi hi; NPL == 3: lo hi, hi lo, mid mid, mid hi, hi mid, hi hi */ \
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[NPLA - 1][i], bp[tk][0][jn], acc[i][jn], 0, 0, 0); \
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0][i], bp[tk][NPLA - 1][jn], acc[i][jn], 0, 0, 0); \
+                    if (NPL == 3) {                                                    \
+                        constexpr int MID = NPL == 3 ? 1 : 0;                          \
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[MID][i], bp[tk][MID][jn], acc[i][jn], 0, 0, 0); \
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[MID][i], bp[tk][0][jn], acc[i][jn], 0, 0, 0); \
+                        acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0][i], bp[tk][MID][jn], acc[i][jn], 0, 0, 0); \
+                    }                                                                  \
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0][i], bp[tk][0][jn], acc[i][jn], 0, 0, 0); \
                 }                                                                      \
         }                                                                              \
         TMAT_PIN()                                                                     \
@@ -430,6 +459,13 @@ static void launch_conv_ks(const ConvArgs &a, int M, int Ho, int Wo, hipStream_t
             hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, true, 1>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt);
         else
             hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, false, 1>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt);
+        return;
+    }
+    if (a.prec == 2) {
+        if (a.relu_in)
+            hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, true, 2>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt);
+        else
+            hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, false, 2>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt);
         return;
     }
     if (a.relu_in)

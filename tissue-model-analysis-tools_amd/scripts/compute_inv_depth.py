@@ -142,6 +142,15 @@ def main(argv=None):
 
     rows = []
     failed = False
+    pending = []
+
+    def flush_pending():
+        # every step is per slice: stacks of one shape go through the classifiers together (InvDepthEnsemble.predict_stacks)
+        for (si_, _), probs in zip(pending, ens.predict_stacks([im for _, im in pending])):     # (Z, n_pred_models): yhatp_m of compute_inv_depth.py:154
+            for z, (inv_prob, inv_label) in enumerate(inv_depth.ensemble_predictions(probs, cls_thresh)):
+                rows.append((si_ * (1 << 20) + z, inv_label, float(inv_prob), 0.0))       # float32 -> float64 is exact; back below
+        pending.clear()
+
     stack_ids = sorted(zstack_paths)              # a deterministic order the ranks agree on (the reference keeps glob order)
     for si in distributed.shard_indices(len(stack_ids), rank, ws):
         zstack_id = stack_ids[int(si)]
@@ -158,9 +167,11 @@ def main(argv=None):
             break
         if img.ndim == 2:
             img = img[None]
-        probs = ens.predict_stack(img)                              # (Z, n_pred_models): yhatp_m of compute_inv_depth.py:154
-        for z, (inv_prob, inv_label) in enumerate(inv_depth.ensemble_predictions(probs, cls_thresh)):
-            rows.append((int(si) * (1 << 20) + z, inv_label, float(inv_prob), 0.0))       # float32 -> float64 is exact; back below
+        pending.append((int(si), img))
+        if sum(len(im) for _, im in pending) >= 128:
+            flush_pending()
+    if not failed:
+        flush_pending()
 
     try:
         gathered = distributed.gather_rows_ragged(rows, failed=failed)

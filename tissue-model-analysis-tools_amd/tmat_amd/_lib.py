@@ -227,9 +227,9 @@ class Handle:
         check(lib().tmat_set_input_norm(self._h, int(on), float(norm_mean or 0.0), float(norm_std if on else 1.0)), "tmat_set_input_norm")
 
     def set_precision(self, mode="f32"):
-        """arithmetic of the UNet's dense convolutions: "f32" (bit-exact contract, default) or "bf16x3" (opt-in split
+        """arithmetic of the UNet's dense convolutions: "f32" (bit-exact contract, default) "bf16x3" or "bf16x6" (opt-in split
         precision on the bf16 matrix cores, include/tmat.h:tmat_set_precision)"""
-        modes = {"f32": 0, "bf16x3": 1}
+        modes = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
         if mode not in modes:
             raise ValueError(f"precision must be one of {sorted(modes)}")
         check(lib().tmat_set_precision(self._h, modes[mode]), "tmat_set_precision")

@@ -44,6 +44,27 @@ def layer_plan(last_layer: str = LAST_LAYER_DEFAULT):
     return plan
 
 
+def flops_per_slice(weights, size: int = 256) -> float:
+    """convolution FLOPs (2 per multiply-add) of one forward of the classifier on a size x size slice: conv1 at size / 2, the
+    max-pool halves it again, stages 3.. halve it in their first block (stride in c1 and in the shortcut c0)"""
+    total, res = 0.0, size // 2
+    kh, kw, ci, co = weights["conv1.w"].shape
+    total += 2.0 * res * res * kh * kw * ci * co
+    res //= 2
+    stage_seen = set()
+    for name, w in weights.items():
+        if not name.endswith(".w") or name in ("conv1.w", "fc.w"):
+            continue
+        blk, conv = name.split(".")[0], name.split(".")[1]
+        stage, b = int(blk[1]), int(blk[3:])
+        if stage > 2 and b == 1 and stage not in stage_seen:
+            stage_seen.add(stage)
+            res //= 2                            # this stage's first block strides (its c1 and c0 already produce the halved map)
+        kh, kw, ci, co = w.shape
+        total += 2.0 * res * res * kh * kw * ci * co
+    return total
+
+
 def synth_resnet_weights(seed: int = 0, last_layer: str = LAST_LAYER_DEFAULT) -> "OrderedDict[str, np.ndarray]":
     """random-init weights of the architecture (there is no network for ImageNet / fine-tuned checkpoints): He-normal
     convolutions, BatchNormalization statistics near identity with a damped last BN per block so 13 residual blocks keep the
@@ -103,6 +124,29 @@ class InvDepthEnsemble:
         check(lib().tmat_inv_depth_predict(self.handle.raw, ptr(ids), len(ids), ptr(a), a.shape[0], a.shape[1], a.shape[2], self.size, ptr(probs),
                                            ptr(x) if return_input else None), "tmat_inv_depth_predict")
         return (probs, x) if return_input else probs
+
+
+    def predict_stacks(self, stacks, max_slices: int = 128):
+        """several stacks -> list of (Z_i, n_models) probabilities.  Every step of the tool is per slice (data_prep.py:17-61,
+        compute_inv_depth.py:150-154), so stacks of one shape and dtype are concatenated along Z and go through the classifiers
+        together, up to `max_slices` per call: larger launches, same per-slice results as predict_stack on each stack."""
+        out = [None] * len(stacks)
+        i = 0
+        while i < len(stacks):
+            a0 = np.asarray(stacks[i])
+            j, nsl = i + 1, a0.shape[0]
+            while j < len(stacks) and np.asarray(stacks[j]).shape[1:] == a0.shape[1:] and np.asarray(stacks[j]).dtype == a0.dtype \
+                    and nsl + np.asarray(stacks[j]).shape[0] <= max_slices:
+                nsl += np.asarray(stacks[j]).shape[0]
+                j += 1
+            probs = self.predict_stack(np.concatenate([np.asarray(s) for s in stacks[i:j]]) if j > i + 1 else a0)
+            z0 = 0
+            for k in range(i, j):
+                zk = np.asarray(stacks[k]).shape[0]
+                out[k] = probs[z0:z0 + zk]
+                z0 += zk
+            i = j
+        return out
 
 
 def best_model_indices(best_ensemble_dir, n_models: int, n_pred_models: int):

@@ -22,8 +22,8 @@ sys.path.insert(0, str(REPO / "tissue-model-analysis-tools_amd"))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--images", type=int, default=256)
-    ap.add_argument("--stacks", type=int, default=8)
+    ap.add_argument("--images", type=int, default=512, help="BASELINE config #5: 512 images")
+    ap.add_argument("--stacks", type=int, default=16, help="16 stacks x 32 slices = 512 images for the invasion-depth tool")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
@@ -45,6 +45,13 @@ def main():
     line = {"metric": "images/sec through compute_cell_area (1024x1024 uint16 -> 512 -> GMM threshold -> area)", "value": a.images / dt, "unit": "images/s",
             "n_gpus": 1, "steps": a.steps, "warmup": 1, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64 (EM on the histogram) / u16", "data": "synthetic", "config": {"workload": f"{a.images} images, host buffers in, batches of 64", "sd_coef": 0.0}}
+    # roofline of the tool as a whole: HBM-bound by construction -- algorithmic bytes per image = the 1024^2 u16 input (2 MB) read once
+    # + the 512^2 u16 down-sampled image written and read twice (histogram, threshold: 1.5 MB) + the 512^2 u8 result (0.25 MB);
+    # the host-pointer entry moves the same 2 MB over PCIe first, which is what bounds this measurement (63 GB/s spec)
+    alg_bytes = 1024 * 1024 * 2 + 3 * 512 * 512 * 2 + 512 * 512
+    line["roofline"] = {"bound": "hbm", "achieved": alg_bytes * a.images / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
+                        "frac": alg_bytes * a.images / dt / 1e9 / 8000.0, "traffic": None,
+                        "note": "whole tool, PCIe inclusive (2 MB/image of H2D at <= 63 GB/s = at most 31 500 images/s); per kernel see profiles/r03_config5_kernel_stats.csv"}
     if not a.no_cpu:
         from oracle import cellarea as ca
         c0 = time.perf_counter()
@@ -58,16 +65,20 @@ def main():
     ws = [inv_depth.synth_resnet_weights(s) for s in range(3)]
     ens = inv_depth.InvDepthEnsemble(h, ws)
     probs = ens.predict_stack(stacks[0])
+    batch = [stacks[k % 2] for k in range(a.stacks)]
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        for k in range(a.stacks):
-            probs = ens.predict_stack(stacks[k % 2])
+        all_probs = ens.predict_stacks(batch)                # stacks of one shape ride together, 128 slices per call
     dt = (time.perf_counter() - t0) / a.steps
+    probs = all_probs[a.stacks - 1]
     nsl = a.stacks * 32
-    flops = 0.0
+    flops = inv_depth.flops_per_slice(ws[0], 256) * 3 * nsl
     line = {"metric": "Z slices/sec through compute_inv_depth (3 x ResNet50 conv4_block6_out at 256x256)", "value": nsl / dt, "unit": "slices/s", "n_gpus": 1,
             "steps": a.steps, "warmup": 1, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic", "config": {"workload": f"{a.stacks} stacks of 32 x 512 x 512 u16, host buffers in; 3 ensemble members, random-init weights"}}
+            "data": "synthetic", "config": {"workload": f"{a.stacks} stacks of 32 x 512 x 512 u16, host buffers in, 4 stacks per call; 3 ensemble members, random-init weights"},
+            "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flops / dt / 1e12 / 157.3, "traffic": None,
+                         "note": "convolution FLOPs of the three ResNet50(conv4_block6_out) members (2 MACs, stem included) over the whole call: upload, resize, "
+                                 "preparation, stem, pooling and head are inside the time"}}
     if not a.no_cpu:
         from oracle import resnet as orr
         c0 = time.perf_counter()

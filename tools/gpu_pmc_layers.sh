@@ -1,6 +1,9 @@
 #!/bin/bash
 # dev tool (GPU box): per-dispatch PMC figures of one UNet forward over a full pass: shader clock, MFMA busy, LDS conflicts,
 # wait buckets.  Separate rocprofv3 --pmc runs per counter group, each with --kernel-trace only.
+# Normalisation (stated here because the raw sums are not fractions): GRBM_GUI_ACTIVE is summed over the 8 XCDs, so the
+# shader clock is GUI / 8 / duration; SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, so the matrix-pipe busy
+# fraction is MFMA_BUSY / (GUI / 8 x 1024); the SQ_WAIT_* / SQ_ACTIVE_* buckets are fractions of SQ_WAVE_CYCLES.
 # Usage: bash tools/gpu_pmc_layers.sh <tag> [patches] [kernel-name filter]
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmcl_$1
@@ -31,8 +34,10 @@ for k, v in rows:
     name = v["name"].replace("tmat::", "").replace("void ", "").split("(")[0][:44]
     keys = [c for c in v if c != "name"]
     if "GRBM_GUI_ACTIVE" in v:
-        g = v["GRBM_GUI_ACTIVE"]
-        print(f"{d/1e3:8.3f} ms clock {g/d/1e3 if d else 0:5.2f} GHz mfma_busy/gui {v.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/g if g else 0:6.3f} sq_busy/gui {v.get('SQ_BUSY_CYCLES',0)/g if g else 0:6.3f}  {name}")
+        # rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs and SQ_VALU_MFMA_BUSY_CYCLES summed over the 1024 SIMDs
+        # (256 CUs x 4): clock = GUI / 8 / duration; matrix-pipe busy fraction = MFMA_BUSY / (GUI / 8 * 1024)
+        g = v["GRBM_GUI_ACTIVE"] / 8.0
+        print(f"{d/1e3:8.3f} ms clock {g/d/1e3 if d else 0:5.2f} GHz mfma_busy {v.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/(g*1024.0) if g else 0:6.3f}  {name}")
     else:
         wc = v.get("SQ_WAVE_CYCLES", 1) or 1
         print(f"{d/1e3:8.3f} ms wait_any {v.get('SQ_WAIT_ANY',0)/wc:5.2f} wait_inst {v.get('SQ_WAIT_INST_ANY',0)/wc:5.2f} active {v.get('SQ_ACTIVE_INST_ANY',0)/wc:5.2f} wait_lds {v.get('SQ_WAIT_INST_LDS',0)/wc:5.2f} "

@@ -29,4 +29,14 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE S
   rm -rf $OUT/pmc_$tag
   echo "pmc $tag done"
 done
+# per-layer durations of one 1600-patch forward, f32 and the opt-in bf16x3 path (rocprofv3 --kernel-trace of tools/gpu_quick.py)
+cd $ROOT
+bash tools/gpu_layers.sh ${R}_f32 1600 > /dev/null 2>&1 && cp gpurun_out/layers_${R}_f32/layers.txt $OUT/f32_layers.txt
+TMAT_PRECISION=bf16x3 bash tools/gpu_layers.sh ${R}_alt 1600 > /dev/null 2>&1 && cp gpurun_out/layers_${R}_alt/layers.txt $OUT/alt_layers.txt
+cd /tmp
+TMAT_PRECISION=bf16x3 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/alt_trace -- python3 $ROOT/tools/gpu_quick.py 1600 2 > $OUT/alt_quick.log 2>&1 || echo "alt trace failed"
+find $OUT/alt_trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/alt_kernel_stats.csv || true
+rm -rf $OUT/alt_trace
+cd $ROOT
+bash tools/gpu_pmc_layers.sh $R 1600 kernel > $OUT/pmc_layers.txt 2>&1 || echo "pmc layers failed"
 ls -la $OUT
