@@ -396,6 +396,14 @@ int tmat_zproj_dev(tmat_handle h, const uint16_t *stacks_dev, int n, int Z, int 
 int tmat_set_precision(tmat_handle h, int mode);
 
 /*
+ * UNetXceptionPatchSegmentor's optional input normalisation, x = (x - norm_mean) / norm_std in float32 (reference
+ * models.py:600-612, 636-637; keys norm_mean / norm_std of the model config), applied on the device in front of
+ * predict_img_with_smooth_windowing by every entry point that runs it (tmat_predict_smooth, tmat_segment_batch,
+ * tmat_analyze_batch*).  Off by default (the shipped unet_patch_segmentor_1.json has no such keys).
+ */
+int tmat_set_input_norm(tmat_handle h, int on, double norm_mean, double norm_std);
+
+/*
  * Timing hook for bench.py's roofline line: accumulated HIP-event time (ms) and launch count of
  * the dominant kernel -- tmat::conv_mfma_kernel<128, 128, 4, 2, 3, false>, the 3x3 implicit-GEMM MFMA
  * convolution instantiation that runs 3 of the 8 transposed-conv layers -- since the last reset, measured
