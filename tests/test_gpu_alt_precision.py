@@ -25,7 +25,7 @@ def test_error_against_a_float64_evaluation(alt_handle, weights):
     """what "f32-equivalent" means for bf16x6: against the as-written graph evaluated in float64 (PyTorch-CPU), the error of
     the bf16x6 path is of the size of the f32 path's own (both are summation-order noise of float32 accumulation), while
     bf16x3 carries the 2^-16 representation error on top"""
-    import torch
+    from conftest import forward_torch_child
     from oracle import unet as ou
     x = np.random.RandomState(33).uniform(0, 1, (2, 320, 320)).astype(np.float32)
     got = {}
@@ -33,7 +33,7 @@ def test_error_against_a_float64_evaluation(alt_handle, weights):
         alt_handle.set_precision(mode)
         got[mode] = alt_handle.unet_predict(x).astype(np.float64)
     assert np.array_equal(got["f32"].astype(np.float32).view(np.uint32), ou.forward_exact(weights, x).view(np.uint32))
-    ref = np.asarray(ou.forward_torch(weights, x, dtype=torch.float64), np.float64)
+    ref = np.asarray(forward_torch_child(x, "float64"), np.float64)
     err = {mode: float(np.abs(got[mode] - ref).max()) for mode in got}
     print(f"\nmax |pred - float64 reference| on 2 patches: f32 {err['f32']:.3e}, bf16x3 {err['bf16x3']:.3e}, bf16x6 {err['bf16x6']:.3e}")
     assert err["f32"] < 2e-5 and err["bf16x6"] < 2e-5
@@ -45,7 +45,7 @@ def test_error_against_a_float64_evaluation(alt_handle, weights):
 def test_patches_close_to_f32_and_to_the_as_written_graph(alt_handle, weights, mode, atol):
     """bf16x6 carries the whole 24-bit mantissa: its outputs sit within a few f32 ulps of the f32 path's (the as-written graph
     itself differs from the exact path by 4e-6: the comparison with it keeps the looser bound)"""
-    from oracle import unet as ou
+    from conftest import forward_torch_child
     rs = np.random.RandomState(21)
     x = rs.uniform(0, 1, (4, 320, 320)).astype(np.float32)
     x[1, :, 100:] = 0.0
@@ -56,7 +56,7 @@ def test_patches_close_to_f32_and_to_the_as_written_graph(alt_handle, weights, m
     print(f"\n{mode} vs f32 on 4 patches: max |d pred| = {d:.3e}, differing outputs {int((alt != f32).sum())} of {alt.size}")
     assert d < atol
     assert (alt != f32).any(), f"{mode} returned the f32 bits: the split-precision kernels did not run"
-    ref = ou.forward_torch(weights, x)
+    ref = forward_torch_child(x)
     d_t = float(np.abs(alt.astype(np.float64) - ref).max())
     print(f"{mode} vs the as-written PyTorch-CPU graph: max |d pred| = {d_t:.3e}")
     assert d_t < PRED_ATOL

@@ -84,41 +84,58 @@ def test_mirror_api(handle, weights, images, oracle_runs):
     seg.handle.close()
 
 
-def test_gather_rows_over_rccl_single_rank(handle):
-    """tmat_gather_rows on a one-rank RCCL communicator created here through ctypes: the gathered rows are the local rows"""
-    import ctypes as C
-    from tmat_amd import _lib
-    L = _lib.lib()
-    try:
-        rccl = C.CDLL("librccl.so.1")
-    except OSError:
-        rccl = C.CDLL("/opt/rocm/lib/librccl.so")
-    hip = C.CDLL("libamdhip64.so")
+RCCL_CHILD = r"""
+import ctypes as C, sys
+sys.path[:0] = [r"{repo}", r"{repo}/tissue-model-analysis-tools_amd"]
+from tmat_amd import _lib
+L = _lib.lib()
+handle = _lib.Handle(None, 0)
+try:
+    rccl = C.CDLL("librccl.so.1")
+except OSError:
+    rccl = C.CDLL("/opt/rocm/lib/librccl.so")
+hip = C.CDLL("libamdhip64.so")
 
-    class UniqueId(C.Structure):
-        _fields_ = [("internal", C.c_char * 128)]
-    uid, comm = UniqueId(), C.c_void_p()
-    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
-    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
-    rows = (_lib.Row * 5)()
-    for i in range(5):
-        rows[i].index, rows[i].count, rows[i].total_px, rows[i].avg_px = 100 + i, 3 * i, 1.5 * i, 0.25 * i
-    nbytes = C.sizeof(rows)
-    din, dout = C.c_void_p(), C.c_void_p()
-    _lib.check(L.tmat_dev_alloc(handle.raw, nbytes, C.byref(din)), "alloc")
-    _lib.check(L.tmat_dev_alloc(handle.raw, nbytes, C.byref(dout)), "alloc")
-    _lib.check(L.tmat_dev_upload(handle.raw, din, C.byref(rows), nbytes), "upload")
-    _lib.check(L.tmat_gather_rows(comm, din, 5, dout, None), "gather")
-    assert hip.hipDeviceSynchronize() == 0
-    got = (_lib.Row * 5)()
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    assert hip.hipMemcpy(C.byref(got), dout, nbytes, 2) == 0           # hipMemcpyDeviceToHost
-    assert [(r.index, r.count, r.total_px, r.avg_px) for r in got] == [(r.index, r.count, r.total_px, r.avg_px) for r in rows]
-    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
-    rccl.ncclCommDestroy(comm)
-    _lib.check(L.tmat_dev_free(handle.raw, din), "free")
-    _lib.check(L.tmat_dev_free(handle.raw, dout), "free")
+class UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+uid, comm = UniqueId(), C.c_void_p()
+assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+rows = (_lib.Row * 5)()
+for i in range(5):
+    rows[i].index, rows[i].count, rows[i].total_px, rows[i].avg_px = 100 + i, 3 * i, 1.5 * i, 0.25 * i
+nbytes = C.sizeof(rows)
+din, dout = C.c_void_p(), C.c_void_p()
+_lib.check(L.tmat_dev_alloc(handle.raw, nbytes, C.byref(din)), "alloc")
+_lib.check(L.tmat_dev_alloc(handle.raw, nbytes, C.byref(dout)), "alloc")
+_lib.check(L.tmat_dev_upload(handle.raw, din, C.byref(rows), nbytes), "upload")
+_lib.check(L.tmat_gather_rows(comm, din, 5, dout, None), "gather")
+assert hip.hipDeviceSynchronize() == 0
+got = (_lib.Row * 5)()
+hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+assert hip.hipMemcpy(C.byref(got), dout, nbytes, 2) == 0           # hipMemcpyDeviceToHost
+assert [(r.index, r.count, r.total_px, r.avg_px) for r in got] == [(r.index, r.count, r.total_px, r.avg_px) for r in rows]
+rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+rccl.ncclCommDestroy(comm)
+_lib.check(L.tmat_dev_free(handle.raw, din), "free")
+_lib.check(L.tmat_dev_free(handle.raw, dout), "free")
+handle.close()
+print("gathered 5 rows over RCCL")
+"""
+
+
+def test_gather_rows_over_rccl_single_rank(tmp_path):
+    """tmat_gather_rows on a one-rank RCCL communicator created through ctypes: the gathered rows are the local rows.  Runs as a
+    host program of its own (a child process with the ROCm installation's librccl and nothing else): a process that has
+    already imported torch has torch's bundled ROCm runtime mapped, and a system librccl loaded after it cannot initialise."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    script = tmp_path / "rccl_child.py"
+    script.write_text(RCCL_CHILD.replace("{repo}", str(Path(__file__).resolve().parents[1])))
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "gathered 5 rows over RCCL" in r.stdout, r.stdout + r.stderr
 
 
 def test_rows_within_north_star_tolerance_of_the_as_written_network(handle, weights, images):
