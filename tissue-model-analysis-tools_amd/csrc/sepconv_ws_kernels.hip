@@ -66,7 +66,10 @@ __device__ long long ws_diag[256 * 12 * 8];
 #define WS_STAMP(k) { const long long now_ = (long long)__builtin_readcyclecounter(); dsum[k] += now_ - dlast; dlast = now_; }
 #define WS_DIAG_DECL long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = (long long)__builtin_readcyclecounter();
 #define WS_DIAG_FLUSH() if (lane == 0 && blockIdx.x < 256) { for (int k = 0; k < 8; k++) ws_diag[((size_t)blockIdx.x * 12 + wave) * 8 + k] = dsum[k]; }
+__device__ long long ws_tl[12 * 2 * 10];         // absolute stamps of workgroup 0's waves in steps 9 (mid tile) and 11 (tile end)
+#define WS_TL(k) if (lane == 0 && blockIdx.x == 0 && (s == 9 || s == 11)) ws_tl[(wave * 2 + (s == 11)) * 10 + (k)] = (long long)__builtin_readcyclecounter();
 #else
+#define WS_TL(k)
 #define WS_STAMP(k)
 #define WS_DIAG_DECL
 #define WS_DIAG_FLUSH()
@@ -207,27 +210,40 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             WS_STAMP(2)
         };
+        // One round = two output rows (acc0: row y, acc1: row y + 1) from the window rows y .. y + 3.  The chains keep the (ky, kx)
+        // order; what moves is WHEN the next round's rows are requested: row y is dead after acc0's first three taps and row y + 1
+        // after the next six FMA groups, so the reads of rows y + 4 and y + 5 go out there and land under the remaining taps --
+        // a round no longer starts by waiting for its own LDS reads (only one wave per SIMD runs in this phase, nothing else
+        // would hide that latency).
+        auto taps3 = [&](float4 &acc, const float4 *row, int ky) {
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                const float4 v = row[kx], w = wt[ky * 3 + kx];
+                acc.x = fmaf(v.x, w.x, acc.x); acc.y = fmaf(v.y, w.y, acc.y);
+                acc.z = fmaf(v.z, w.z, acc.z); acc.w = fmaf(v.w, w.w, acc.w);
+            }
+        };
         auto compute = [&](int stage) {
             float *As = smem + (stage ? WS_A1 : WS_A0);
+            relu_row(win[0]); relu_row(win[1]);
 #pragma unroll
             for (int y = 0; y < 8; y += 2) {
-                if (y) {
-                    load_row(y + 2, win[(y + 2) & 3]);
-                    load_row(y + 3, win[(y + 3) & 3]);
-                }
-                WS_PIN()
-                if (y == 0) { relu_row(win[0]); relu_row(win[1]); }
-                relu_row(win[(y + 2) & 3]);
-                relu_row(win[(y + 3) & 3]);
+                float4 *w0 = win[y & 3], *w1 = win[(y + 1) & 3], *w2 = win[(y + 2) & 3], *w3 = win[(y + 3) & 3];
                 float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
-#pragma unroll
-                for (int tp = 0; tp < 9; tp++) {
-                    const float4 v0 = win[(y + tp / 3) & 3][tp % 3], v1 = win[(y + 1 + tp / 3) & 3][tp % 3];
-                    acc0.x = fmaf(v0.x, wt[tp].x, acc0.x); acc0.y = fmaf(v0.y, wt[tp].y, acc0.y);
-                    acc0.z = fmaf(v0.z, wt[tp].z, acc0.z); acc0.w = fmaf(v0.w, wt[tp].w, acc0.w);
-                    acc1.x = fmaf(v1.x, wt[tp].x, acc1.x); acc1.y = fmaf(v1.y, wt[tp].y, acc1.y);
-                    acc1.z = fmaf(v1.z, wt[tp].z, acc1.z); acc1.w = fmaf(v1.w, wt[tp].w, acc1.w);
-                }
+                taps3(acc0, w0, 0);
+                WS_PIN()
+                if (y + 4 < 10) load_row(y + 4, w0);
+                WS_PIN()
+                taps3(acc0, w1, 1);
+                taps3(acc1, w1, 0);
+                WS_PIN()
+                if (y + 5 < 10) load_row(y + 5, w1);
+                WS_PIN()
+                relu_row(w2);
+                taps3(acc0, w2, 2);
+                taps3(acc1, w2, 1);
+                relu_row(w3);
+                taps3(acc1, w3, 2);
                 *reinterpret_cast<float4 *>(As + aoff0 + (y >> 1) * 1024) = acc0;
                 *reinterpret_cast<float4 *>(As + aoff1 + (y >> 1) * 1024) = acc1;
                 WS_PIN()
@@ -242,18 +258,23 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
         WS_BAR()
         int cc = 0;
         for (int s = 0; s < total; s++) {
+            WS_TL(0)
             if (s + 1 < total) fetch((s + 1) & 1);
             WS_STAMP(3)
+            WS_TL(1)
             WS_BAR()                                         // consumers: MFMAs of step s issued
             WS_STAMP(4)
+            WS_TL(2)
             if (s + 1 < total) compute((s + 1) & 1);
             WS_STAMP(5)
+            WS_TL(3)
             if (++cc == nchunks) {
                 cc = 0;
                 if (POOL) WS_BAR()                           // inside the consumers' pooling epilogue
             }
             WS_BAR()                                         // step s + 1's operands are in LDS
             WS_STAMP(6)
+            WS_TL(4)
         }
 #ifdef WS_DIAG
         dsum[7] = total;
@@ -287,6 +308,7 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
     // lane's channel and tile row), the tile in the buffer base and (pixel, channel group) in the scalar offset -- in the
     // vector phase every vector instruction of the 8 consumer waves delays the producers' depthwise arithmetic and vice versa.
     const int CoutB = a.Cout * 4;
+    const float relu_lo = a.relu_out ? 0.f : -__builtin_inff();        // fmaxf(v, relu_lo): ReLU or identity without a select per value
     const unsigned vo_pool = (unsigned)(4 * h * a.Cout + r) * 4u;        // pooled pixel 4h (+ q), channel r (+ 32 jn)
     float rv[4][4];
     auto load_resid = [&](int jj) {
@@ -304,27 +326,42 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
         }
     };
 
-    // ---- epilogue of one tile: straight from the accumulators (C/D layout: column = lane & 31 = output channel, row
-    // rho = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) = the MFMA row, i.e. PIXMAP's r)
-    // register e of a 32x32 accumulator is MFMA row rho = (e & 3) + 8 (e >> 2) + 4 h = tile pixel (y, x) with x = e and
-    // y = h for e in {0-3, 12-15}, 1 - h for e in 4..11 (PIXMAP): two per-lane offsets, everything else scalar
-    const unsigned vo_y0 = (unsigned)(h * a.W * a.Cout + r) * 4u, vo_y1 = (unsigned)((1 - h) * a.W * a.Cout + r) * 4u;
-    auto store_tile = [&](int jj) {
+    // ---- epilogue of one tile.  C/D layout of a 32x32 accumulator: column = lane & 31 = output channel, register e = MFMA row
+    // rho = (e & 3) + 8 (e >> 2) + 4 h = tile pixel (y, x) with x = e and y = h for e in {0-3, 12-15}, 1 - h for e in 4..11 (PIXMAP).
+    // Plain epilogue: 64 one-dword stores per wave and tile (two 128-byte lines each) kept the CU's one texture-address path busy
+    // for ~8 000 cycles per tile (512 store instructions, ~16 cycles each).  The values go through the wave's PRIVATE 4 KiB of the
+    // A stage the tile's last step has just consumed instead -- [32 tile pixels][32 channels], one 32-channel slab (jn) at a time --
+    // and leave as 16-byte stores: 16 store instructions per wave and tile, each 8 pixels x one full 128-byte line.  No barrier:
+    // LDS operations of one wave execute in order.
+    unsigned vo_t[4];            // tile pixel 8 i + (lane >> 3) of this wave's two rows, channel quad lane & 7
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int pix = 8 * i + (lane >> 3);
+        vo_t[i] = (unsigned)(((pix >> 4) * a.W + (pix & 15)) * a.Cout + (lane & 7) * 4) * 4u;
+    }
+    auto store_tile = [&](int jj, float *xw) {
         const int mt = jj / nNt, nt = jj - mt * nNt;
         const int n = mt / TPP, tr = mt - n * TPP;
         const int ty0 = (tr / TW) * 16, tx0 = (tr % TW) * 16;
         const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(
             (void *)(a.out + ((size_t)n * a.H * a.W + (size_t)(ty0 + 2 * wave) * a.W + tx0) * a.Cout + nt * 128), 0, 0x7fffffff, 0x00020000);
+        float *xl = xw + r;
+        const float *xr = xw + lane * 4;
 #pragma unroll
         for (int jn = 0; jn < 4; jn++) {
             const float sc = scv[jn], sh = shv[jn];
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                float v = fmaf(acc[jn][e], sc, sh);
-                if (a.relu_out) v = fmaxf(v, 0.f);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsO, (e >= 4 && e < 12) ? vo_y1 : vo_y0, e * CoutB + jn * 128, 0);
+            for (int e = 0; e < 16; e++) {      // register e = tile pixel (y, x = e), y = h for e in {0-3, 12-15}, 1 - h for e in 4..11 (PIXMAP)
+                const int yy = (e >= 4 && e < 12) ? 1 - h : h;
+                xl[(yy * 16 + e) * 32] = fmaxf(fmaf(acc[jn][e], sc, sh), relu_lo);
                 acc[jn][e] = 0.f;
             }
+            float4 o[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) o[i] = *reinterpret_cast<const float4 *>(xr + i * 256);
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o[i]), rsO, vo_t[i], jn * 128, 0);
         }
     };
 
@@ -350,8 +387,7 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
             float v[16];
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                v[e] = fmaf(acc[jn][e], sc, sh);
-                if (a.relu_out) v[e] = fmaxf(v[e], 0.f);
+                v[e] = fmaxf(fmaf(acc[jn][e], sc, sh), relu_lo);
                 acc[jn][e] = 0.f;
             }
             // columns 8 h + k, k = 0..7: own register 8 h + k; the other half wave's register of the same index holds the other
@@ -410,20 +446,16 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
 
     WS_DIAG_DECL
     WS_BAR()                                                 // step 0's operands are in LDS
-    int cj = j0, cc = 0;
-    for (int s = 0; s < total; s++) {
-        const int stage = s & 1;
-        WS_STAMP(0)
-        if (cc == 0) load_scale_shift(cj);
-        if (POOL && cc == nchunks - 1) load_resid(cj);
-        const float *As = smem + (stage ? WS_A1 : WS_A0) + aoffc;
-        const float *Bs = smem + (stage ? WS_B1 : WS_B0) + boffc;
-        float4 av[2], bv[2][4];
-#define WS_READ(g)                                                                                              \
+    // Fragment reads.  The pointwise weights of step s + 1 are complete in LDS when the MFMA phase of step s ends (the producers
+    // wait for their LDS-DMA before barrier X), the A operand only when its vector phase ends (barrier Y).  The consumers idle
+    // through the vector phase, so they read the weight fragments of the next step's first two k groups THERE; after barrier Y
+    // only the two A reads stand between a wave and its first MFMA.
+    float4 av[2], bv[2][4];
+#define WS_READ_A(g) av[(g) & 1] = *reinterpret_cast<const float4 *>(As + ((((2 * (g)) + h) ^ key) * 4));
+#define WS_READ_B(g, Bp)                                                                                        \
         {                                                                                                       \
             const int slot = (((2 * (g)) + h) ^ key) * 4;                                                       \
-            av[(g) & 1] = *reinterpret_cast<const float4 *>(As + slot);                                         \
-            _Pragma("unroll") for (int jn = 0; jn < 4; jn++) bv[(g) & 1][jn] = *reinterpret_cast<const float4 *>(Bs + jn * 1024 + slot); \
+            _Pragma("unroll") for (int jn = 0; jn < 4; jn++) bv[(g) & 1][jn] = *reinterpret_cast<const float4 *>((Bp) + jn * 1024 + slot); \
         }
 #define WS_MM(g)                                                                                                \
         {                                                                                                       \
@@ -432,37 +464,72 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
             _Pragma("unroll") for (int jn = 0; jn < 4; jn++) acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(g) & 1].z, bv[(g) & 1][jn].z, acc[jn], 0, 0, 0); \
             _Pragma("unroll") for (int jn = 0; jn < 4; jn++) acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(g) & 1].w, bv[(g) & 1][jn].w, acc[jn], 0, 0, 0); \
         }
-        WS_READ(0)
+    {
+        const float *B0 = smem + WS_B0 + boffc;
+        WS_READ_B(0, B0)
+        WS_READ_B(1, B0)
+    }
+    int cj = j0, cc = 0;
+    for (int s = 0; s < total; s++) {
+        const int stage = s & 1;
+        WS_STAMP(0)
+        if (cc == 0) load_scale_shift(cj);
+        if (POOL && cc == nchunks - 1) load_resid(cj);
+        const float *As = smem + (stage ? WS_A1 : WS_A0) + aoffc;
+        const float *Bs = smem + (stage ? WS_B1 : WS_B0) + boffc;
+        WS_TL(0)
+        WS_READ_A(0)
+        WS_READ_A(1)
         WS_PIN()
-        WS_READ(1)
+#ifdef WS_DIAG
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        WS_TL(1)
         WS_PIN()
+#endif
         WS_MM(0)
         WS_PIN()
-        WS_READ(2)
+        WS_TL(2)
+        WS_READ_A(2)
+        WS_READ_B(2, Bs)
         WS_PIN()
         WS_MM(1)
         WS_PIN()
-        WS_READ(3)
+        WS_TL(3)
+        WS_READ_A(3)
+        WS_READ_B(3, Bs)
         WS_PIN()
         WS_MM(2)
         WS_PIN()
+        WS_TL(4)
         WS_MM(3)
         WS_PIN()
-#undef WS_READ
-#undef WS_MM
+        WS_TL(5)
         WS_STAMP(1)
         WS_BAR()                                             // vector phase: the producers compute the next step's A operand
         WS_STAMP(2)
+        WS_TL(6)
         if (++cc == nchunks) {
             cc = 0;
             if (POOL) store_tile_pool(cj, smem + (stage ? WS_A : 0));
-            else store_tile(cj);
+            else store_tile(cj, smem + (stage ? WS_A1 : WS_A0) + wave * 1024);
             cj++;
         }
+        WS_PIN()
+        if (s + 1 < total) {
+            const float *Bn = smem + (stage ? WS_B0 : WS_B1) + boffc;
+            WS_READ_B(0, Bn)
+            WS_READ_B(1, Bn)
+        }
+        WS_PIN()
         WS_STAMP(3)
+        WS_TL(7)
         WS_BAR()
         WS_STAMP(4)
+        WS_TL(8)
     }
+#undef WS_READ_A
+#undef WS_READ_B
+#undef WS_MM
 #ifdef WS_DIAG
     dsum[7] = total;
 #endif
@@ -508,6 +575,17 @@ static void launch_ws_any(const WsArgs &a, int relu_in, hipStream_t s)
         fprintf(stderr, "[wsdiag] H %d Cin %d Cout %d pool %d | consumer per step: top %.0f mfma %.0f barX %.0f epilogue %.0f barY %.0f | producer per step: issue %.0f vmcnt0 %.0f rows %.0f barX %.0f compute %.0f barY %.0f | steps/wave %.0f\n",
                 a.H, a.Cin, a.Cout, (int)POOL, cs[0] / cst, cs[1] / cst, cs[2] / cst, cs[3] / cst, cs[4] / cst,
                 ps[0] / pst, ps[1] / pst, ps[2] / pst, (ps[3] + ps[4]) / pst, ps[5] / pst, ps[6] / pst, cst / (nb * 8.0));
+        static long long tl[12 * 2 * 10];
+        hipMemcpyFromSymbol(tl, HIP_SYMBOL(ws_tl), sizeof(tl));
+        for (int st = 0; st < 2; st++) {
+            long long t0 = tl[st * 10];
+            for (int w = 0; w < 12; w++) if (tl[(w * 2 + st) * 10] < t0) t0 = tl[(w * 2 + st) * 10];
+            for (int w = 0; w < 12; w++) {
+                fprintf(stderr, "[wstl] step %d wave %2d:", st ? 11 : 9, w);
+                for (int k = 0; k < (w < 8 ? 9 : 5); k++) fprintf(stderr, " %6lld", tl[(w * 2 + st) * 10 + k] - t0);
+                fprintf(stderr, "\n");
+            }
+        }
     }
 #endif
 }

@@ -12,7 +12,7 @@ if [ "$2" != "pmc-only" ]; then
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -1 $OUT/bench.json | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline --no-alt > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
 rm -rf $OUT/trace            # the raw per-dispatch trace is large; the stats summary is what is kept
 echo "kernel-trace done"

@@ -13,6 +13,11 @@ REPO = Path(__file__).resolve().parents[1]
 DOM = "conv_mfma_kernel<128, 128, 4, 2, 3, false>"
 
 
+def is_dom(name):
+    """the f32 instantiation of the dominant kernel (the template has a trailing precision parameter since round 3: ', 0>')"""
+    return "conv_mfma_kernel<128, 128, 4, 2, 3, false>" in name or "conv_mfma_kernel<128, 128, 4, 2, 3, false, 0>" in name
+
+
 def main(rnd):
     src = REPO / "gpurun_out" / f"profiles_{rnd}"
     dst = REPO / "profiles"
@@ -29,7 +34,8 @@ def main(rnd):
             "dmt_sort_kernel", "invert_u8", "weight_kernel", "gauss_axis", "zoom_clip", "rescale255", "minmax_kernel")
 
     def stream_of(name):
-        return "side (low priority; summed duration = mostly queueing under the next pass's network)" if any(k in name for k in side) else "main"
+        base = name.replace("void ", "").split("(")[0].split("<")[0].replace("tmat::", "")
+        return "side (low priority; summed duration = mostly queueing under the next pass's network)" if any(base.startswith(k) for k in side) else "main"
     out["top_kernels_by_total_time"] = [
         {"kernel": r["Name"].split("(")[0].replace("void ", ""), "calls": int(r["Calls"]), "total_ms": round(float(r["TotalDurationNs"]) / 1e6, 1),
          "avg_ms": round(float(r["AverageNs"]) / 1e6, 3), "percent": float(r["Percentage"]), "stream": stream_of(r["Name"])} for r in rows[:10]]
@@ -39,7 +45,7 @@ def main(rnd):
         {"kernel": r["Name"].split("(")[0].replace("void ", ""), "calls": int(r["Calls"]), "avg_ms": round(float(r["AverageNs"]) / 1e6, 3),
          "percent_of_main_stream_time": round(100.0 * float(r["TotalDurationNs"]) / main_total, 2)} for r in main_rows[:10]]
     for r in rows:
-        if DOM in r["Name"]:
+        if is_dom(r["Name"]):
             out["rocprof_calls"] = int(r["Calls"])
             out["rocprof_avg_ms"] = float(r["AverageNs"]) / 1e6
             out["rocprof_total_ms"] = float(r["TotalDurationNs"]) / 1e6
@@ -59,7 +65,7 @@ def main(rnd):
         if not p.exists():
             return vals
         for r in csv.DictReader(open(p)):
-            if r["Counter_Name"] == cname and DOM in r["Kernel_Name"]:
+            if r["Counter_Name"] == cname and is_dom(r["Kernel_Name"]):
                 vals.append(float(r["Counter_Value"]))
         # the run starts with an 8-patch warm-up forward: keep the full-size (1600-patch) launches only
         return [v for v in vals if v >= 0.25 * max(vals)] if vals else vals
