@@ -210,11 +210,10 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             WS_STAMP(2)
         };
-        // One round = two output rows (acc0: row y, acc1: row y + 1) from the window rows y .. y + 3.  The chains keep the (ky, kx)
-        // order; what moves is WHEN the next round's rows are requested: row y is dead after acc0's first three taps and row y + 1
-        // after the next six FMA groups, so the reads of rows y + 4 and y + 5 go out there and land under the remaining taps --
-        // a round no longer starts by waiting for its own LDS reads (only one wave per SIMD runs in this phase, nothing else
-        // would hide that latency).
+        // One round = two output rows (acc0: row y, acc1: row y + 1) from the window rows y .. y + 3, each chain in (ky, kx)
+        // order.  (Tried and rejected, +3.6 ms over the four layers: requesting rows y + 4 / y + 5 in the middle of a round, as
+        // soon as rows y / y + 1 are dead, so that they land under the remaining taps -- at tile-end steps the producers then
+        // queue their LDS reads behind the consumers' epilogue traffic twice per round instead of once.)
         auto taps3 = [&](float4 &acc, const float4 *row, int ky) {
 #pragma unroll
             for (int kx = 0; kx < 3; kx++) {
@@ -225,25 +224,23 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
         };
         auto compute = [&](int stage) {
             float *As = smem + (stage ? WS_A1 : WS_A0);
-            relu_row(win[0]); relu_row(win[1]);
 #pragma unroll
             for (int y = 0; y < 8; y += 2) {
-                float4 *w0 = win[y & 3], *w1 = win[(y + 1) & 3], *w2 = win[(y + 2) & 3], *w3 = win[(y + 3) & 3];
+                if (y) {
+                    load_row(y + 2, win[(y + 2) & 3]);
+                    load_row(y + 3, win[(y + 3) & 3]);
+                }
+                WS_PIN()
+                if (y == 0) { relu_row(win[0]); relu_row(win[1]); }
+                relu_row(win[(y + 2) & 3]);
+                relu_row(win[(y + 3) & 3]);
                 float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
-                taps3(acc0, w0, 0);
-                WS_PIN()
-                if (y + 4 < 10) load_row(y + 4, w0);
-                WS_PIN()
-                taps3(acc0, w1, 1);
-                taps3(acc1, w1, 0);
-                WS_PIN()
-                if (y + 5 < 10) load_row(y + 5, w1);
-                WS_PIN()
-                relu_row(w2);
-                taps3(acc0, w2, 2);
-                taps3(acc1, w2, 1);
-                relu_row(w3);
-                taps3(acc1, w3, 2);
+                taps3(acc0, win[y & 3], 0);
+                taps3(acc0, win[(y + 1) & 3], 1);
+                taps3(acc0, win[(y + 2) & 3], 2);
+                taps3(acc1, win[(y + 1) & 3], 0);
+                taps3(acc1, win[(y + 2) & 3], 1);
+                taps3(acc1, win[(y + 3) & 3], 2);
                 *reinterpret_cast<float4 *>(As + aoff0 + (y >> 1) * 1024) = acc0;
                 *reinterpret_cast<float4 *>(As + aoff1 + (y >> 1) * 1024) = acc1;
                 WS_PIN()

@@ -41,6 +41,24 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// Exact division of a non-negative int (< 2^31) by a launch constant d >= 2 as one v_mul_hi_u32 and one shift: with
+// l = ceil(log2 d) and mul = ceil(2^(31 + l) / d) < 2^32, floor(n mul / 2^(31 + l)) = floor(n / d) for every n < 2^31 (the
+// excess n e / (d 2^(31 + l)), e = mul d - 2^(31 + l) < d, stays below 2^-l <= 1 / d).  A runtime `/` costs ~35 vector
+// instructions, and vector instructions do not run beside the other workgroup's f32 MFMAs on the SIMD: the pixel <-> (n, y, x)
+// conversions of the prologue and of the sub-pixel / residual epilogue were 3-8 % of a short-K tile.
+struct FastDiv {
+    unsigned mul;
+    int sh;
+};
+static FastDiv make_fastdiv(int d)
+{
+    int l = 0;
+    while ((1ll << l) < d) l++;
+    const unsigned long long num = 1ull << (31 + l);
+    return FastDiv{(unsigned)((num + (unsigned long long)d - 1) / (unsigned long long)d), l - 1};
+}
+__device__ __forceinline__ int fdiv(int n, FastDiv f) { return (int)(__umulhi((unsigned)n, f.mul) >> f.sh); }
+
 // PREC = 0: f32 operands on v_mfma_f32_32x32x2_f32 (the bit-exact path, everything above).
 // PREC = 1, 2: split precision on the bf16 matrix cores, opt-in (tmat_set_precision), f32 accumulation:
 //   1 "bf16x3": x = hi + lo (hi = rne_bf16(x), lo = rne_bf16(x - hi)); a w ~ a_lo w_hi + a_hi w_lo + a_hi w_hi: three
@@ -58,7 +76,7 @@ template <int BM, int BN, int WM, int WN, int KS, bool RELU, int PREC = 0>
 #ifndef TMAT_CONV_WPS
 #define TMAT_CONV_WPS 4     // waves per SIMD the 8-wave conv kernel is compiled for (VGPR budget 512 / this)
 #endif
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 > 65536 ? 2 : WM * WN == 8 ? TMAT_CONV_WPS : 2)) void conv_mfma_kernel(ConvArgs a, int M, int Ho, int Wo, int nMt, int nNt)
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 > 65536 ? 2 : WM * WN == 8 ? TMAT_CONV_WPS : 2)) void conv_mfma_kernel(ConvArgs a, int M, int Ho, int Wo, int nMt, int nNt, FastDiv dHW, FastDiv dW)
 {
     // KS (1, 2 or 3) is a template parameter so that the 3x3 and the pointwise instantiations are distinct kernels
     // (distinct names in rocprofv3 traces: the 3x3 <128,128,2,2,3,*> instantiations are the dominant kernel).
@@ -90,8 +108,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
     // nNt column tiles of one pixel tile to the same XCD so its L2 serves the re-read A pixels.
     const int b = blockIdx.x;
     const int xcd = b & 7, j = b >> 3;
+#ifdef TMAT_VAR_NMAP      // experiment: an XCD keeps ONE column tile's weights (L2-resident) and shares the pixel tiles with 8 / nNt - 1 others
+    const bool nstat = nNt > 1 && nNt <= 8 && (8 % nNt) == 0;
+    const int nt = nstat ? xcd % nNt : j % nNt;
+    const int mt = nstat ? j * (8 / nNt) + xcd / nNt : (j / nNt) * 8 + xcd;
+#else
     const int nt = j % nNt;
     const int mt = (j / nNt) * 8 + xcd;
+#endif
     if (mt >= nMt) return;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -117,9 +141,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
     // K = Cin as small as 64, i.e. two chunks per tile, so a division-heavy prologue would show)
     const bool flat = KS == 1 && a.stride == 1;
     auto stored_pixel = [&](int m) {     // linear index of the stored pixel that output pixel m is centred on
-        const int n = m / (Ho * Wo);
+        const int n = fdiv(m, dHW);
         const int r = m - n * (Ho * Wo);
-        const int yo = r / Wo;
+        const int yo = fdiv(r, dW);
         return (n * a.h + yo * a.stride) * a.w + (r - yo * Wo) * a.stride;
     };
     const int p0 = flat ? m0 : __builtin_amdgcn_readfirstlane(stored_pixel(m0));
@@ -135,27 +159,39 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
             continue;
         }
         const int mm = ok ? m : m0;
-        const int n = mm / (Ho * Wo);
+        const int n = fdiv(mm, dHW);
         const int r = mm - n * (Ho * Wo);
-        const int yo = r / Wo;
+        const int yo = fdiv(r, dW);
         const int y = yo * a.stride, x = (r - yo * Wo) * a.stride;
         pv[i] = (unsigned)(((n * a.h + y) * a.w + x - p0) * a.Cin + c4) * 4u;
-        unsigned msk = 0;
-        if (ok) {
-            if (KS == 3) {
-#pragma unroll
-                for (int tp = 0; tp < 9; tp++) {
-                    const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
-                    if (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) msk |= 1u << tp;
-                }
-            } else if (KS == 2) {
-#pragma unroll
-                for (int tp = 0; tp < 4; tp++) {
-                    const int yy = y + spy - 1 + (tp >> 1), xx = x + spx - 1 + (tp & 1);
-                    if (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) msk |= 1u << tp;
-                }
-            } else msk = 1u;
+        // tap masks without branches: bit ky * 3 + kx is set when row y + ky - 1 and column x + kx - 1 lie inside the image
+        unsigned msk = 1u;
+#ifdef TMAT_OLD_MASKS
+        if (KS == 3) {
+            msk = 0;
+            for (int tp = 0; tp < 9; tp++) {
+                const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+                if (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) msk |= 1u << tp;
+            }
+        } else if (KS == 2) {
+            msk = 0;
+            for (int tp = 0; tp < 4; tp++) {
+                const int yy = y + spy - 1 + (tp >> 1), xx = x + spx - 1 + (tp & 1);
+                if (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) msk |= 1u << tp;
+            }
         }
+#else
+        if (KS == 3) {
+            const unsigned ym = (y > 0 ? 0x007u : 0u) | 0x038u | (y + 1 < a.h ? 0x1C0u : 0u);
+            const unsigned xm = (x > 0 ? 0x049u : 0u) | 0x092u | (x + 1 < a.w ? 0x124u : 0u);
+            msk = ym & xm;
+        } else if (KS == 2) {       // tap tp: row y + spy - 1 + (tp >> 1), column x + spx - 1 + (tp & 1)
+            const unsigned ym = (y + spy > 0 ? 0x3u : 0u) | (y + spy < a.h ? 0xCu : 0u);
+            const unsigned xm = (x + spx > 0 ? 0x5u : 0u) | (x + spx < a.w ? 0xAu : 0u);
+            msk = ym & xm;
+        }
+#endif
+        if (!ok) msk = 0u;
         pm[i] = msk;
     }
     const __amdgpu_buffer_rsrc_t rsA =
@@ -174,6 +210,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
     const int ldsw = wave * 8 * KC;                  // this wave's 8 rows (1 KiB) inside an RP-row pass
 
     int ld_cb = 0, ld_tap = 0;
+#ifdef TMAT_ABL_A9        // timing ablation (wrong results): the A tile is fetched for one tap per channel block only -- what a halo tile could save at most
+#define TMAT_ABL_A9_COND (ld_tap == 0)
+#else
+#define TMAT_ABL_A9_COND true
+#endif
 #define TMAT_DMA_A(i)                                                                                        \
     if (i < NPA) {                                                                                           \
         const unsigned vo = (pm[i] & tbit) ? pv[i] : OOB;                                                    \
@@ -193,8 +234,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
         const int soB = ld_tap * wtap + ld_cb * KC * 4;                                \
         const int soBp = ld_tap * (wtap >> 1) + ld_cb * KC * 2;      /* bf16 planes */     \
         const unsigned tbit = 1u << ld_tap;                                            \
+        if (TMAT_ABL_A9_COND) {                                                        \
         TMAT_DMA_A(0) TMAT_DMA_A(1) TMAT_DMA_A(2) TMAT_DMA_A(3)                        \
         TMAT_DMA_A(4) TMAT_DMA_A(5) TMAT_DMA_A(6) TMAT_DMA_A(7)                        \
+        }                                                                              \
         TMAT_DMA_B(0) TMAT_DMA_B(1) TMAT_DMA_B(2) TMAT_DMA_B(3)                        \
         if (++ld_tap == taps) { ld_tap = 0; ld_cb++; }                                 \
     }
@@ -402,6 +445,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
         if (a.scale) sc = *reinterpret_cast<const float4 *>(a.scale + co);
         const int rH = Ho >> a.rs, rW = Wo >> a.rs;
         const int wrow0 = wm * (BM / WM);
+        // Addressing without vector arithmetic where the output is linear in m (everything but the sub-pixel scatter): uniform
+        // 64-bit base (tile, iteration) + a 32-bit per-lane offset that is fixed for the kernel (global_store ... saddr form).
+        // (raw_buffer_store_b128 with the tile in the descriptor and the iteration in soffset looked equivalent and was NOT: the
+        // network's outputs differed in the last bits from run to run, tests/test_gpu_unet.py; left aside, not understood.)
+        const bool full = m0 + BM <= M;
+        const unsigned vo = (unsigned)(r0 * a.Cout + cv) * 4u;
+        const float relu_lo = a.relu_out ? 0.f : -__builtin_inff();
 #pragma unroll
         for (int pass = 0; pass < NPASS; pass++) {
             if (wrow0 / EPR == pass) {
@@ -415,34 +465,42 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
                     }
             }
             __syncthreads();
+            const size_t tbase = (size_t)(m0 + pass * EPR) * a.Cout + n0;
+            char *const obase = reinterpret_cast<char *>(a.out + tbase);
+            const char *const rbase = reinterpret_cast<const char *>(a.resid + tbase);       // used for rs == 0 only
 #pragma unroll 4
             for (int it = 0; it < EPR / RPI; it++) {
                 const int row = it * RPI + r0;
                 const int m = m0 + pass * EPR + row;
-                if (m >= M) continue;
+                const bool ok = full || m < M;
+                const size_t so = (size_t)(it * RPI) * a.Cout * 4;
                 float4 v = *reinterpret_cast<const float4 *>(Cs + row * BN + cv);
                 if (a.scale) { v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w); }
                 else { v.x = v.x + sh.x; v.y = v.y + sh.y; v.z = v.z + sh.z; v.w = v.w + sh.w; }
                 if (a.resid) {
-                    size_t ridx = (size_t)m;
+                    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (a.rs) {
-                        const int n = m / (Ho * Wo);
-                        const int rr = m - n * (Ho * Wo);
-                        const int y = rr / Wo, x = rr - y * Wo;
-                        ridx = ((size_t)n * rH + (y >> a.rs)) * rW + (x >> a.rs);
-                    }
-                    const float4 rv = *reinterpret_cast<const float4 *>(a.resid + ridx * a.Cout + co);
+                        if (ok) {
+                            const int n = fdiv(m, dHW);
+                            const int rr = m - n * (Ho * Wo);
+                            const int y = fdiv(rr, dW), x = rr - y * Wo;
+                            const size_t ridx = ((size_t)n * rH + (y >> a.rs)) * rW + (x >> a.rs);
+                            rv = *reinterpret_cast<const float4 *>(a.resid + ridx * a.Cout + co);
+                        }
+                    } else if (ok) rv = *reinterpret_cast<const float4 *>(rbase + so + vo);
                     v.x = v.x + rv.x; v.y = v.y + rv.y; v.z = v.z + rv.z; v.w = v.w + rv.w;
                 }
-                if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                size_t oidx = (size_t)m;
+                v.x = fmaxf(v.x, relu_lo); v.y = fmaxf(v.y, relu_lo); v.z = fmaxf(v.z, relu_lo); v.w = fmaxf(v.w, relu_lo);
                 if (KS == 2) {      // scatter to the parity class's pixels of the (2 Ho, 2 Wo) output
-                    const int n = m / (Ho * Wo);
-                    const int rr = m - n * (Ho * Wo);
-                    const int y = rr / Wo, x = rr - y * Wo;
-                    oidx = ((size_t)n * 2 * Ho + 2 * y + spy) * (2 * Wo) + 2 * x + spx;
+                    if (ok) {
+                        const int n = fdiv(m, dHW);
+                        const int rr = m - n * (Ho * Wo);
+                        const int y = fdiv(rr, dW), x = rr - y * Wo;
+                        const size_t oidx = ((size_t)n * 2 * Ho + 2 * y + spy) * (2 * Wo) + 2 * x + spx;
+                        *reinterpret_cast<float4 *>(a.out + oidx * a.Cout + co) = v;
+                    }
                 }
-                *reinterpret_cast<float4 *>(a.out + oidx * a.Cout + co) = v;
+                else if (ok) *reinterpret_cast<float4 *>(obase + so + vo) = v;
             }
             if (pass + 1 < NPASS) __syncthreads();
         }
@@ -454,24 +512,25 @@ static void launch_conv_ks(const ConvArgs &a, int M, int Ho, int Wo, hipStream_t
 {
     int nMt = (M + BM - 1) / BM, nNt = a.Cout / BN;
     dim3 grid(((nMt + 7) / 8) * 8 * nNt, KS == 2 ? 4 : 1);
+    const FastDiv dHW = make_fastdiv(Ho * Wo), dW = make_fastdiv(Wo);
     if (a.prec == 1) {
         if (a.relu_in)
-            hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, true, 1>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt);
+            hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, true, 1>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt, dHW, dW);
         else
-            hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, false, 1>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt);
+            hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, false, 1>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt, dHW, dW);
         return;
     }
     if (a.prec == 2) {
         if (a.relu_in)
-            hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, true, 2>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt);
+            hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, true, 2>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt, dHW, dW);
         else
-            hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, false, 2>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt);
+            hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, false, 2>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt, dHW, dW);
         return;
     }
     if (a.relu_in)
-        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, true>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt);
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, true>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt, dHW, dW);
     else
-        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, false>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt);
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, false>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt, dHW, dW);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -502,7 +561,7 @@ bool launch_conv(const ConvArgs &a, hipStream_t s)
     if (!((a.ksize == 3 && a.stride == 1) || (a.ksize == 2 && a.stride == 1 && !a.resid) ||
           (a.ksize == 1 && (a.stride == 1 || a.stride == 2))) || a.Cin % 32 || a.Cout % 64 ||
         ((a.ksize * a.ksize * (a.Cin / 32)) & 1) || Mll <= 0 ||
-        Mll > 0x7fffffffLL / 2 || (a.resid && a.rs && ((Ho | Wo) & 1))) {
+        Mll > 0x7fffffffLL / 2 || (a.resid && a.rs && ((Ho | Wo) & 1)) || Wo < 2) {
         set_error("launch_conv: unsupported shape");
         return false;
     }
