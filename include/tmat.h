@@ -274,6 +274,19 @@ int tmat_field_stats(tmat_handle h, const float *field, int fh, int fw, float gr
                      int smoothing_window_px, int min_branch_length_px, int max_branch_length_px, int remove_isolated,
                      int64_t index, tmat_row *row);
 
+/* The same with MorseGraph's pruning_mask (topology.py: branches that end inside the mask are trimmed): the Z-stack
+ * branch with --detect-well passes the inverse of the shrunken well mask (compute_branches.py:243, 412-420).
+ * pruning_mask (fh, fw) u8 host, nonzero = prune; NULL = none. */
+int tmat_field_stats_pruned(tmat_handle h, const float *field, int fh, int fw, float graph_thresh_1, float graph_thresh_2,
+                            int smoothing_window_px, int min_branch_length_px, int max_branch_length_px, int remove_isolated,
+                            const uint8_t *pruning_mask, int64_t index, tmat_row *row);
+
+/* skimage.transform.resize(x, (n, out_h, out_w), order=1, preserve_range=True, anti_aliasing=True) of n integer images
+ * (scikit-image >= 0.19: anti-aliasing gaussian + grid-mode linear zoom, clipped to the input's range), float64 out.
+ * compute_branches.py:232-238 resizes the max projection of a Z stack with it before make_well_mask.
+ * imgs (n, H, W) u16 host (8-bit images widened); out (n, out_h, out_w) f64 host. */
+int tmat_resize_aa_u16(tmat_handle h, const uint16_t *imgs, int n, int H, int W, int out_h, int out_w, double *out);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Cell-area tool: reference scripts/compute_cell_area.py:29-87, 164-178 and
  * fl_tissue_model_tools/preprocessing.py:44-93 (csrc/cellarea_kernels.hip).  A handle from tmat_create_plain is enough.

@@ -258,13 +258,31 @@ def vessel_field(vol01: np.ndarray, return_stages=False, hessian="gaussian_deriv
     return field
 
 
-def analyze_stack(stack: np.ndarray, config: dict, image_width_microns: float, hessian="gaussian_derivatives"):
-    """(count, total_px, avg_px) of one Z stack through the Sato branch + the graph stages of the 2-D path"""
-    from . import dmt, morse, pipeline
+def resize_aa(img: np.ndarray, out_hw) -> np.ndarray:
+    """skimage.transform.resize(img, out_hw, order=1, preserve_range=True, anti_aliasing=True) of a 2-D integer image (scikit-image
+    >= 0.19: the two scipy calls of stack_prepare on the 2-D array, clipped to the input's range), float64"""
+    a = np.asarray(img).astype(np.float64)
+    factors = np.divide(a.shape, tuple(int(v) for v in out_hw))
+    filt = ndi.gaussian_filter(a, np.maximum(0, (factors - 1) / 2), cval=0, mode="mirror")
+    out = ndi.zoom(filt, [1 / f for f in factors], order=1, mode="mirror", cval=0, grid_mode=True)
+    return np.clip(out, a.min(), a.max())
+
+
+def analyze_stack(stack: np.ndarray, config: dict, image_width_microns: float, hessian="gaussian_derivatives", detect_well=False, well_seed=0,
+                  return_masks=False):
+    """(count, total_px, avg_px) of one Z stack through the Sato branch + the graph stages of the 2-D path.  detect_well
+    (compute_branches.py:227-243): the well mask of the resized max projection; only its shrunken form enters, as MorseGraph's pruning mask"""
+    from . import dmt, morse, pipeline, wellmask
     out_hw = morph.dsamp_shape(stack.shape[-2:], 384)
+    pruning = well = None
+    if detect_well:
+        well, shrunken = wellmask.make_well_mask(resize_aa(stack.max(0), out_hw), seed=well_seed)
+        pruning = np.logical_not(shrunken)
     field = vessel_field(stack_prepare(stack, out_hw), hessian=hessian)
     f255 = morph.rescale_intensity(field, (0, 255)).astype(np.float32)
     V, E = dmt.compute_dmt_graph(f255, float(config.get("graph_thresh_1", 5)), float(config.get("graph_thresh_2", 10)))
     sw, mn, mx = pipeline.px_params(config, 384, image_width_microns)
-    _, n, tot, avg = morse.morse_stats(V, E, field.shape, sw, mn, mx, bool(config.get("remove_isolated_branches", False)), None)
+    _, n, tot, avg = morse.morse_stats(V, E, field.shape, sw, mn, mx, bool(config.get("remove_isolated_branches", False)), pruning)
+    if return_masks:
+        return (n, tot, avg), well, pruning
     return n, tot, avg

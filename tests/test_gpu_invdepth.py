@@ -49,6 +49,23 @@ def test_full_model_and_stack_pipeline(plain):
     assert len({round(float(p), 3) for p in probs.ravel()}) > 2            # the synthetic models do not saturate
 
 
+def test_exact_halving_of_a_512_slice_takes_cv2s_area_path(plain):
+    """a 512 x 512 slice at the configured 256 x 256 is an exact halving on both axes: cv2.resize then replaces INTER_LINEAR by
+    INTER_AREA's integer mean (imgproc/src/resize.cpp), which oracle/cellarea.py:resize_linear_u16 restates (hand-derived vectors in
+    tests/test_gpu_cellarea.py); the preparation of the invasion-depth tool must follow (tools/bench_config5.py's stacks are 512 x 512)"""
+    from oracle import resnet as orr
+    from tmat_amd import inv_depth, synth
+    ens = inv_depth.InvDepthEnsemble(plain, [inv_depth.synth_resnet_weights(0, "conv2_block1_out")])
+    stack = synth.synth_stack(4, 2, 512, 512, n_vessels=8)
+    probs, x = ens.predict_stack(stack, return_input=True)
+    ox = orr.prep_inv_depth_imgs(stack, 256)
+    a = stack[0].astype(np.uint32)
+    small = ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.float64)
+    g = (small - small.min()) / (small.max() - small.min()) * 255.0
+    assert np.array_equal(ox[0, :, :, 0], (g - 103.939).astype(np.float32))
+    assert np.array_equal(x.view(np.uint32), ox.view(np.uint32))
+
+
 def test_bad_weights_and_arguments(plain):
     from tmat_amd import _lib, inv_depth
     w = inv_depth.synth_resnet_weights(0, "conv2_block1_out")

@@ -132,6 +132,50 @@ def test_analyze_stack_row_equals_oracle(plain, hessian):
     assert n > 0
 
 
+def _well_stack(seed, Z=4, h=300, w=400):
+    """a synthetic stack whose vessels sit inside a round well that is brighter than its surroundings"""
+    from tmat_amd import synth
+    st = synth.synth_stack(seed, Z, h, w, n_vessels=14).astype(np.float64)
+    yy, xx = np.mgrid[0:h, 0:w]
+    inside = (xx - w * 0.5) ** 2 / (w * 0.42) ** 2 + (yy - h * 0.52) ** 2 / (h * 0.42) ** 2 < 1
+    out = np.where(inside, st * 0.6 + 14000.0, st * 0.05 + 900.0)
+    return np.clip(out, 0, 65535).astype(np.uint16)
+
+
+@pytest.mark.parametrize("shape,out_hw,bits", [((210, 260), (62, 77), 16), ((96, 100), (96, 100), 16), ((300, 128), (150, 64), 8)])
+def test_resize_aa_of_a_projection(plain, shape, out_hw, bits):
+    """tmat_resize_aa_u16 (compute_branches.py:232-238: resize of the max projection, float64 out) against the two scipy calls"""
+    from oracle import sato as osato
+    from tmat_amd import sato
+    rs = np.random.RandomState(shape[0])
+    img = ndi.gaussian_filter(rs.uniform(0, 1, shape) ** 4, 2)
+    img = (img / img.max() * (2 ** bits - 1)).astype(np.uint16 if bits == 16 else np.uint8)
+    got = sato.resize_aa(plain, img, out_hw)
+    want = osato.resize_aa(img, out_hw)
+    assert got.dtype == np.float64 and np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+def test_stack_detect_well_prunes_the_graph_like_the_oracle(plain):
+    """--detect-well on a Z stack (compute_branches.py:227-243, 412-420): masks equal to the oracle's (whose well detection is pinned to
+    the reference), and the pruned row equals the oracle's and differs from the unpruned one"""
+    from oracle import sato as osato
+    from tmat_amd import branches, sato
+    stack = _well_stack(11)
+    cfg = {"graph_thresh_1": 5, "graph_thresh_2": 10, "graph_smoothing_window": 12, "min_branch_length": 12, "remove_isolated_branches": False}
+    width_um = 1000.0
+    sw, mn, mx = branches.graph_px_params(cfg, 384, width_um)
+    field = sato.stack_field(plain, stack)
+    well, pruning = sato.stack_well_masks(plain, stack, field.shape, seed=3)
+    (on, otot, oavg), owell, opruning = osato.analyze_stack(stack, cfg, width_um, detect_well=True, well_seed=3, return_masks=True)
+    assert 0.4 < owell.mean() < 0.95, "the test stack should have a real well"
+    assert np.array_equal(well, owell) and np.array_equal(pruning, opruning)
+    row = sato.field_stats(plain, field, 5, 10, sw, mn, mx, False, pruning_mask=pruning)
+    assert row == (on, otot, oavg) and on > 0
+    plain_row = sato.field_stats(plain, field, 5, 10, sw, mn, mx, False)
+    assert plain_row == osato.analyze_stack(stack, cfg, width_um)
+    assert plain_row != row, "the pruning mask should remove something in this case"
+
+
 def test_bad_arguments(plain):
     from tmat_amd import _lib, sato
     with pytest.raises(ValueError):

@@ -126,6 +126,29 @@ def test_script_analyzes_z_stacks_through_the_sato_branch(tmp_path):
         assert np.array(Image.open(vdir / "vesselness_image.png")).shape == (300, 384)
 
 
+def test_script_detect_well_on_a_z_stack(tmp_path):
+    """-w for Z-stack inputs (compute_branches.py:227-243): the CSV row equals the oracle's row with the pruning mask, well_mask.png is
+    the oracle's well mask"""
+    from PIL import Image
+    from oracle import sato as osato
+    from test_gpu_sato import _well_stack
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir()
+    st = _well_stack(11)
+    for z, sl in enumerate(st):
+        Image.fromarray(sl).save(ind / f"plate_z{z}.tif")
+    r = run([str(ind), str(outd), "--image-width-microns", "1000", "-w", "--well-seed", "3", "--visualizations"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows = read_csv(outd / "branching_analysis.csv")
+    cfg = dict(graph_thresh_1=5, graph_thresh_2=10, graph_smoothing_window=12, min_branch_length=12, remove_isolated_branches=False)
+    (n, tot, avg), well, _ = osato.analyze_stack(st, cfg, 1000.0, detect_well=True, well_seed=3, return_masks=True)
+    from tmat_amd import branches
+    got = rows[1]
+    assert got[0] == "plate" and int(got[1]) == n and n > 0
+    assert float(got[2]) == pytest.approx(branches.pixels_to_microns(tot, 384, 1000.0), rel=1e-12)
+    assert np.array_equal(np.array(Image.open(outd / "visualizations" / "plate" / "well_mask.png")) > 0, well)
+
+
 def test_script_multipage_stacks_threshold_grid_and_legacy_hessian(tmp_path):
     """multi-page TIFF files are stacks too (compute_branches.py:554-559); a threshold grid writes one CSV per configuration
     from ONE vesselness image per stack; --sato-hessian gradient selects the scikit-image <= 0.19 Hessian"""

@@ -234,6 +234,7 @@ static void linear_axis_f(int n_src, int n_dst, std::vector<int> &i0, std::vecto
 }
 __global__ void resize_linear_u16_kernel(const uint16_t *img, int H, int W, int oh, int ow, const int *r0, const int *r1, const float *wr0, const float *wr1,
                                          const int *c0, const int *c1, const float *wc0, const float *wc1, uint16_t *out);      // cellarea_kernels.hip
+__global__ void resize_area2_u16_kernel(const uint16_t *img, int H, int W, uint16_t *out);                                      // cellarea_kernels.hip
 
 }  // namespace tmat
 
@@ -342,7 +343,11 @@ int tmat_inv_depth_predict(tmat_handle hd, const int *model_ids, int n_models, c
         if (!ok) { set_error("tmat_inv_depth_predict: upload failed"); rc = TMAT_E_HIP; }
         else {
             const int blocks = (int)((npx + 255) / 256);
-            hipLaunchKernelGGL(resize_linear_u16_kernel, dim3(blocks < 1024 ? blocks : 1024, Z), dim3(256), 0, s, din, H, W, size, size, dr0, dr1, dwr0, dwr1, dc0, dc1, dwc0, dwc1, dsm);
+            // cv::resize takes INTER_AREA's integer mean for an exact halving on both axes (a 512 x 512 slice at the configured 256 x 256)
+            if (H == 2 * size && W == 2 * size)
+                hipLaunchKernelGGL(resize_area2_u16_kernel, dim3(blocks < 1024 ? blocks : 1024, Z), dim3(256), 0, s, din, H, W, dsm);
+            else
+                hipLaunchKernelGGL(resize_linear_u16_kernel, dim3(blocks < 1024 ? blocks : 1024, Z), dim3(256), 0, s, din, H, W, size, size, dr0, dr1, dwr0, dwr1, dc0, dc1, dwc0, dwc1, dsm);
             hipLaunchKernelGGL(minmax_u16_img_kernel, dim3(Z), dim3(256), 0, s, dsm, (int)npx, mnmx, mnmx + Z);
             hipLaunchKernelGGL(inv_prep_kernel, dim3(blocks < 1024 ? blocks : 1024, Z), dim3(256), 0, s, dsm, (int)npx, mnmx, mnmx + Z, dx);
             for (int mi = 0; mi < n_models && !rc; mi++)

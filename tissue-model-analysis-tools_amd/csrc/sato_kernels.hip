@@ -246,10 +246,12 @@ int stack_zoom_rescale_dev(const double *filtered, const uint16_t *stack_after_g
     hipLaunchKernelGGL((minmax_all_kernel<uint16_t>), rgrid_in, dim3(256), 0, s, stack_after_gauss, nin, mm);
     hipLaunchKernelGGL(minmax_decode_kernel, dim3(1), dim3(1), 0, s, mm, lohi);
     hipLaunchKernelGGL(zoom_stack_kernel, grid_for(nout), dim3(256), 0, s, filtered, H, W, oh, ow, r0, r1, wr0, wr1, c0, c1, wc0, wc1, lohi, zoomed, nout);
-    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, s, mm);
-    hipLaunchKernelGGL((minmax_all_kernel<double>), rgrid_out, dim3(256), 0, s, zoomed, nout, mm);
-    hipLaunchKernelGGL(minmax_decode_kernel, dim3(1), dim3(1), 0, s, mm, lohi + 2);
-    hipLaunchKernelGGL(rescale01_f64_kernel, grid_for(nout), dim3(256), 0, s, zoomed, nout, lohi + 2, vol);
+    if (vol) {                // vol == nullptr: the caller wants the resized values themselves (tmat_resize_aa_u16)
+        hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, s, mm);
+        hipLaunchKernelGGL((minmax_all_kernel<double>), rgrid_out, dim3(256), 0, s, zoomed, nout, mm);
+        hipLaunchKernelGGL(minmax_decode_kernel, dim3(1), dim3(1), 0, s, mm, lohi + 2);
+        hipLaunchKernelGGL(rescale01_f64_kernel, grid_for(nout), dim3(256), 0, s, zoomed, nout, lohi + 2, vol);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -197,12 +197,16 @@ int vessel_field_dev(Ctx *c, const float *vol, int Z, int h, int w, int form, fl
 }
 
 // stack (Z, H, W) u16 on the device (overwritten by its per-slice gaussian) -> vol (Z, oh, ow) f32 on the device
-int stack_prepare_dev(Ctx *c, uint16_t *stack, int Z, int H, int W, int oh, int ow, float *vol, hipStream_t s)
+// skimage.transform.resize(stack, (Z, oh, ow), order=1, preserve_range=True, anti_aliasing=True) of an integer stack (scikit-image
+// >= 0.19: ndi.gaussian_filter(sigma (factor - 1) / 2, 'mirror') + ndi.zoom(order 1, grid_mode) on the 3-D array, the Z axis with sigma 0
+// and zoom 1), clipped to the stack's range: the float64 values in `zoomed` (device, Z oh ow); with `vol` also rescale_intensity(0..1) over
+// the whole stack as float32
+int stack_resize_aa_dev(Ctx *c, const uint16_t *stack, int Z, int H, int W, int oh, int ow, double *zoomed, float *vol, hipStream_t s)
 {
-    const size_t nin = (size_t)Z * H * W, nout = (size_t)Z * oh * ow;
+    const size_t nin = (size_t)Z * H * W;
     Arena A;
     A.drain = s;
-    double *fa = A.get<double>(nin), *fb = A.get<double>(nin), *zoomed = A.get<double>(nout), *lohi = A.get<double>(4);
+    double *fa = A.get<double>(nin), *fb = A.get<double>(nin), *lohi = A.get<double>(4);
     unsigned long long *mm = A.get<unsigned long long>(2);
     std::vector<int> r0, r1, c0, c1;
     std::vector<double> wr0, wr1, wc0, wc1;
@@ -215,13 +219,7 @@ int stack_prepare_dev(Ctx *c, uint16_t *stack, int Z, int H, int W, int oh, int 
     TMAT_HIP(hipMemcpyAsync(dc0, c0.data(), ow * 4, hipMemcpyHostToDevice, s)); TMAT_HIP(hipMemcpyAsync(dc1, c1.data(), ow * 4, hipMemcpyHostToDevice, s));
     TMAT_HIP(hipMemcpyAsync(dwr0, wr0.data(), oh * 8, hipMemcpyHostToDevice, s)); TMAT_HIP(hipMemcpyAsync(dwr1, wr1.data(), oh * 8, hipMemcpyHostToDevice, s));
     TMAT_HIP(hipMemcpyAsync(dwc0, wc0.data(), ow * 8, hipMemcpyHostToDevice, s)); TMAT_HIP(hipMemcpyAsync(dwc1, wc1.data(), ow * 8, hipMemcpyHostToDevice, s));
-    // z1: gaussian(slice, sigma 1, 'nearest') in f64, written back into the integer stack (C truncation)
-    const GaussTable &g1 = gauss_table(c, 1.0, 0, gauss_radius(1.0, 4.0));
-    const double *w1 = table_dev(c, g1);
-    if (!w1) return TMAT_E_HIP;
-    launch_corr1d_u16_f64(stack, fa, (size_t)Z, H, W, w1, g1.r, g1.sym, EXT_NEAREST, s);
-    launch_corr1d_f64_u16(fa, stack, (size_t)Z * H, W, 1, w1, g1.r, g1.sym, EXT_NEAREST, s);
-    // z2: anti-aliasing gaussian over rows and columns ('mirror', sigma (factor - 1) / 2), zoom, clip to the stack's range
+    // anti-aliasing gaussian over rows and columns ('mirror', sigma (factor - 1) / 2), zoom, clip to the stack's range
     const double f0 = (double)H / (double)oh, f1 = (double)W / (double)ow;
     const double s0 = std::max(0.0, (f0 - 1) / 2), s1 = std::max(0.0, (f1 - 1) / 2);
     const double *cur = nullptr;
@@ -240,7 +238,7 @@ int stack_prepare_dev(Ctx *c, uint16_t *stack, int Z, int H, int W, int oh, int 
         else launch_corr1d_u16_f64(stack, fb, (size_t)Z * H, W, 1, wd, t.r, t.sym, EXT_MIRROR, s);
         cur = fb;
     }
-    if (!cur) {               // no smoothing at all (an image at most 384 wide): the zoom reads the stack as f64
+    if (!cur) {               // no smoothing at all (an image at most as wide as the target): the zoom reads the stack as f64
         const double one = 1.0;
         double *w_id = lohi;   // borrowed for a moment: a 1-tap identity kernel
         TMAT_HIP(hipMemcpyAsync(w_id, &one, 8, hipMemcpyHostToDevice, s));
@@ -248,13 +246,29 @@ int stack_prepare_dev(Ctx *c, uint16_t *stack, int Z, int H, int W, int oh, int 
         launch_corr1d_u16_f64(stack, fa, (size_t)Z * H, W, 1, w_id, 0, 1, EXT_MIRROR, s);
         cur = fa;
     }
-    // z3: rescale to 0..1 over the whole stack
     if (stack_zoom_rescale_dev(cur, stack, Z, H, W, oh, ow, dr0, dr1, dwr0, dwr1, dc0, dc1, dwc0, dwc1, zoomed, mm, lohi, vol, s)) {
-        set_error("stack prepare: kernel launch failed");
+        set_error("stack resize: kernel launch failed");
         return TMAT_E_HIP;
     }
     TMAT_HIP(hipStreamSynchronize(s));       // the host tables leave scope
     return TMAT_OK;
+}
+
+int stack_prepare_dev(Ctx *c, uint16_t *stack, int Z, int H, int W, int oh, int ow, float *vol, hipStream_t s)
+{
+    const size_t nin = (size_t)Z * H * W, nout = (size_t)Z * oh * ow;
+    Arena A;
+    A.drain = s;
+    double *fa = A.get<double>(nin), *zoomed = A.get<double>(nout);
+    if (!A.ok) return TMAT_E_HIP;
+    // z1: gaussian(slice, sigma 1, 'nearest') in f64, written back into the integer stack (C truncation)
+    const GaussTable &g1 = gauss_table(c, 1.0, 0, gauss_radius(1.0, 4.0));
+    const double *w1 = table_dev(c, g1);
+    if (!w1) return TMAT_E_HIP;
+    launch_corr1d_u16_f64(stack, fa, (size_t)Z, H, W, w1, g1.r, g1.sym, EXT_NEAREST, s);
+    launch_corr1d_f64_u16(fa, stack, (size_t)Z * H, W, 1, w1, g1.r, g1.sym, EXT_NEAREST, s);
+    // z2 + z3: anti-aliased resize, rescale to 0..1 over the whole stack
+    return stack_resize_aa_dev(c, stack, Z, H, W, oh, ow, zoomed, vol, s);
 }
 
 }  // namespace tmat
@@ -441,7 +455,7 @@ int tmat_vessel_field(tmat_handle hd, const float *vol, int Z, int hh, int ww, i
 
 // common tail of analyze_img from the vesselness image in HBM: rescale_intensity(0..255) (:419), DMT graph, MorseGraph statistics
 static int field_stats_dev(Ctx *c, const float *field, int fh, int fw, float t1, float t2, int smooth, int min_len, int max_len, int remove_isolated,
-                           int64_t index, tmat_row *row, hipStream_t s)
+                           const uint8_t *pruning_mask, int64_t index, tmat_row *row, hipStream_t s)
 {
     const size_t npx = (size_t)fh * fw, nE = dmt_edge_count(fh, fw);
     Arena A;
@@ -467,13 +481,14 @@ static int field_stats_dev(Ctx *c, const float *field, int fh, int fw, float t1,
     int rc = dmt_graph_host_sorted(f255_host.data(), fh, fw, t1, t2, ids_host.data(), m_host, V.data(), cap_v, E.data(), cap_e, &nv, &ne);
     row->index = index; row->count = 0; row->total_px = 0; row->avg_px = 0;
     if (!rc)
-        rc = tmat_morse_stats(V.data(), nv, E.data(), ne, fh, fw, smooth, min_len, max_len, remove_isolated, nullptr, &row->count, &row->total_px,
+        rc = tmat_morse_stats(V.data(), nv, E.data(), ne, fh, fw, smooth, min_len, max_len, remove_isolated, pruning_mask, &row->count, &row->total_px,
                               &row->avg_px, nullptr, 0);
     return rc;
 }
 
-int tmat_field_stats(tmat_handle hd, const float *field, int fh, int fw, float graph_thresh_1, float graph_thresh_2, int smoothing_window_px,
-                     int min_branch_length_px, int max_branch_length_px, int remove_isolated, int64_t index, tmat_row *row)
+int tmat_field_stats_pruned(tmat_handle hd, const float *field, int fh, int fw, float graph_thresh_1, float graph_thresh_2, int smoothing_window_px,
+                            int min_branch_length_px, int max_branch_length_px, int remove_isolated, const uint8_t *pruning_mask, int64_t index,
+                            tmat_row *row)
 {
     Ctx *c = (Ctx *)hd;
     if (!c || !field || !row || fh < 2 || fw < 2) { set_error("tmat_field_stats: bad argument"); return TMAT_E_ARG; }
@@ -484,7 +499,33 @@ int tmat_field_stats(tmat_handle hd, const float *field, int fh, int fw, float g
     if (!A.ok) return TMAT_E_HIP;
     TMAT_HIP(hipMemcpyAsync(df, field, (size_t)fh * fw * 4, hipMemcpyHostToDevice, c->stream));
     return field_stats_dev(c, df, fh, fw, graph_thresh_1, graph_thresh_2, smoothing_window_px, min_branch_length_px, max_branch_length_px, remove_isolated,
-                           index, row, c->stream);
+                           pruning_mask, index, row, c->stream);
+}
+
+int tmat_field_stats(tmat_handle hd, const float *field, int fh, int fw, float graph_thresh_1, float graph_thresh_2, int smoothing_window_px,
+                     int min_branch_length_px, int max_branch_length_px, int remove_isolated, int64_t index, tmat_row *row)
+{
+    return tmat_field_stats_pruned(hd, field, fh, fw, graph_thresh_1, graph_thresh_2, smoothing_window_px, min_branch_length_px, max_branch_length_px,
+                                   remove_isolated, nullptr, index, row);
+}
+
+int tmat_resize_aa_u16(tmat_handle hd, const uint16_t *imgs, int n, int H, int W, int out_h, int out_w, double *out)
+{
+    Ctx *c = (Ctx *)hd;
+    if (!c || !imgs || !out || n < 1 || H < 1 || W < 1 || out_h < 1 || out_w < 1) { set_error("tmat_resize_aa_u16: bad argument"); return TMAT_E_ARG; }
+    TMAT_HIP(hipSetDevice(c->device));
+    const size_t nin = (size_t)n * H * W, nout = (size_t)n * out_h * out_w;
+    Arena A;
+    A.drain = c->stream;
+    uint16_t *ds = A.get<uint16_t>(nin);
+    double *dz = A.get<double>(nout);
+    if (!A.ok) return TMAT_E_HIP;
+    TMAT_HIP(hipMemcpyAsync(ds, imgs, nin * 2, hipMemcpyHostToDevice, c->stream));
+    int rc = stack_resize_aa_dev(c, ds, n, H, W, out_h, out_w, dz, nullptr, c->stream);
+    if (rc) return rc;
+    TMAT_HIP(hipMemcpyAsync(out, dz, nout * 8, hipMemcpyDeviceToHost, c->stream));
+    TMAT_HIP(hipStreamSynchronize(c->stream));
+    return TMAT_OK;
 }
 
 int tmat_analyze_stack(tmat_handle hd, const uint16_t *stack, int Z, int H, int W, int ds_width, int hessian, float graph_thresh_1,
@@ -513,7 +554,7 @@ int tmat_analyze_stack(tmat_handle hd, const uint16_t *stack, int Z, int H, int 
     if (rc) return rc;
     if (field_out) TMAT_HIP(hipMemcpyAsync(field_out, field, npx * 4, hipMemcpyDeviceToHost, s));
     return field_stats_dev(c, field, fh, fw, graph_thresh_1, graph_thresh_2, smoothing_window_px, min_branch_length_px, max_branch_length_px,
-                           remove_isolated, index, row, s);
+                           remove_isolated, nullptr, index, row, s);
 }
 
 int tmat_host_gaussian_kernel1d(double sigma, int order, int radius, double *weights)

@@ -214,14 +214,11 @@ def finish_distributed(ws: int):
 def run_stacks(args, config, paths, out_root: Path, rank: int, ws: int, local_rank: int):
     """Z-stack entries: the Sato branch (compute_branches.py:224-306) on this rank's share of the stacks"""
     from tmat_amd import _lib, branches, distributed, helper, sato
-    if getattr(args, "detect_well", False):
-        # compute_branches.py:231-243 makes the stack's well mask from a float64 anti-aliased resize of the max projection; that
-        # input is not produced by this path yet (the 2-D branch and compute_cell_area.py accept -w)
-        print(f"{FAIL} --detect-well is not available for Z-stack inputs in the accelerated path.", flush=True)
-        sys.exit(1)
     handle = _lib.Handle(None, local_rank)          # this branch needs no segmentation model
     hessian = getattr(args, "sato_hessian", "gaussian_derivatives")
     vis = bool(getattr(args, "visualizations", False))
+    detect_well = bool(getattr(args, "detect_well", False))
+    well_seed = int(getattr(args, "well_seed", 0) or 0)
     ids = sorted(paths)
     fields = {}
 
@@ -253,15 +250,22 @@ def run_stacks(args, config, paths, out_root: Path, rank: int, ws: int, local_ra
             fields["batch"] = batch
         for i, st in enumerate(batch):
             if i not in fields:
-                fields[i] = sato.stack_field(handle, st, DOWNSAMPLE_WIDTH, hessian)
-            rows.append((i,) + sato.field_stats(handle, fields[i], thresh[0], thresh[1], sw_px, min_px, max_px,
-                                                bool(config.get("remove_isolated_branches", False))))
+                field = sato.stack_field(handle, st, DOWNSAMPLE_WIDTH, hessian)
+                # --detect-well (compute_branches.py:231-243): the well mask of the resized max projection only prunes the graph here
+                pruning = sato.stack_well_masks(handle, st, field.shape, well_seed)[1] if detect_well else None
+                fields[i] = (field, pruning)
+            rows.append((i,) + sato.field_stats(handle, fields[i][0], thresh[0], thresh[1], sw_px, min_px, max_px,
+                                                bool(config.get("remove_isolated_branches", False)), pruning_mask=fields[i][1]))
         return rows
 
     def load_and_keep(img_id):
         st = load_fn(img_id)
         if vis:
             branches.save_stack_visualizations(handle, st, out_root / "visualizations" / img_id, hessian)
+            if detect_well:
+                from PIL import Image
+                well = sato.stack_well_masks(handle, st, sato.dsamp_shape(st.shape, DOWNSAMPLE_WIDTH), well_seed)[0]
+                Image.fromarray((well * 255).astype(np.uint8)).save(out_root / "visualizations" / img_id / "well_mask.png")
         return st
 
     # one stack per analysis call (chunk=1): a stack is the unit the reference streams, and it can be gigabytes

@@ -72,6 +72,8 @@ def lib():
     L.tmat_vessel_field.argtypes = [vp, vp, i, i, i, i, vp, vp]
     L.tmat_analyze_stack.argtypes = [vp, vp, i, i, i, i, i, f, f, i, i, i, i, C.c_int64, vp, vp]
     L.tmat_field_stats.argtypes = [vp, vp, i, i, f, f, i, i, i, i, C.c_int64, vp]
+    L.tmat_field_stats_pruned.argtypes = [vp, vp, i, i, f, f, i, i, i, i, vp, C.c_int64, vp]
+    L.tmat_resize_aa_u16.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.tmat_cell_area_batch.argtypes = [vp, vp, i, i, i, i, i, d, vp, vp, vp]
     L.tmat_cell_area_masked.argtypes = [vp, vp, vp, i, i, i, d, vp, vp, vp]
     L.tmat_resize_linear_u16.argtypes = [vp, vp, i, i, i, i, i, vp]
@@ -103,7 +105,7 @@ EXPORTS = [
     "tmat_host_rescale255_f32", "tmat_host_filter_mask", "tmat_host_skeletonize", "tmat_host_medial_axis",
     "tmat_host_permutation", "tmat_host_postprocess",
     "tmat_set_gaussian_table", "tmat_host_gaussian_kernel1d", "tmat_gaussian_f32", "tmat_sato_batch", "tmat_stack_prepare", "tmat_vessel_field",
-    "tmat_analyze_stack", "tmat_field_stats", "tmat_cell_area_batch", "tmat_cell_area_masked", "tmat_resize_linear_u16",
+    "tmat_analyze_stack", "tmat_field_stats", "tmat_field_stats_pruned", "tmat_resize_aa_u16", "tmat_cell_area_batch", "tmat_cell_area_masked", "tmat_resize_linear_u16",
     "tmat_resnet_load", "tmat_resnet_predict", "tmat_inv_depth_predict",
 ]
 

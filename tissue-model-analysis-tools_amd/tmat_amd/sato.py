@@ -165,14 +165,41 @@ def analyze_stack(handle: Handle, stack: np.ndarray, graph_thresh_1, graph_thres
 
 
 def field_stats(handle: Handle, field: np.ndarray, graph_thresh_1, graph_thresh_2, smoothing_window_px, min_branch_length_px,
-                max_branch_length_px=None, remove_isolated=False, index=0):
-    """tmat_field_stats: vesselness image -> (count, total_px, avg_px)"""
+                max_branch_length_px=None, remove_isolated=False, index=0, pruning_mask=None):
+    """tmat_field_stats(_pruned): vesselness image -> (count, total_px, avg_px); pruning_mask (bool, the field's shape) is MorseGraph's
+    `pruning_mask` (compute_branches.py:243, 412-420: the inverse of the shrunken well mask under --detect-well)"""
     f = np.ascontiguousarray(field, np.float32)
     row = Row()
-    check(lib().tmat_field_stats(handle.raw, ptr(f), f.shape[0], f.shape[1], float(graph_thresh_1), float(graph_thresh_2), int(smoothing_window_px),
-                                 int(min_branch_length_px), int(max_branch_length_px or 0), int(bool(remove_isolated)), int(index), C.byref(row)),
-          "tmat_field_stats")
+    pm = None
+    if pruning_mask is not None:
+        pm = np.ascontiguousarray(np.asarray(pruning_mask) > 0, np.uint8)
+        if pm.shape != f.shape:
+            raise ValueError("field_stats: pruning_mask must have the field's shape")
+    check(lib().tmat_field_stats_pruned(handle.raw, ptr(f), f.shape[0], f.shape[1], float(graph_thresh_1), float(graph_thresh_2), int(smoothing_window_px),
+                                        int(min_branch_length_px), int(max_branch_length_px or 0), int(bool(remove_isolated)),
+                                        ptr(pm) if pm is not None else None, int(index), C.byref(row)), "tmat_field_stats_pruned")
     return row.count, row.total_px, row.avg_px
+
+
+def resize_aa(handle: Handle, imgs: np.ndarray, out_hw) -> np.ndarray:
+    """skimage.transform.resize(x, out_hw, order=1, preserve_range=True, anti_aliasing=True) of one (H, W) or n (n, H, W) uint8 / uint16
+    images -> float64 (compute_branches.py:232-238: the max projection of a Z stack before make_well_mask)"""
+    a = np.asarray(imgs)
+    single = a.ndim == 2
+    a = _as_u16_stack(a[None] if single else a)
+    install_gaussian_tables(handle, a.shape[1:], out_hw, sigmas=())
+    out = np.empty((a.shape[0],) + tuple(int(v) for v in out_hw), np.float64)
+    check(lib().tmat_resize_aa_u16(handle.raw, ptr(a), a.shape[0], a.shape[1], a.shape[2], int(out_hw[0]), int(out_hw[1]), ptr(out)), "tmat_resize_aa_u16")
+    return out[0] if single else out
+
+
+def stack_well_masks(handle: Handle, stack: np.ndarray, out_hw, seed=0):
+    """--detect-well for a Z stack (compute_branches.py:227-243): well mask of the anti-alias-resized max projection
+    -> (well_mask, pruning_mask) bool arrays of shape out_hw (pruning = not shrunken well)"""
+    from . import well_mask_generation as wmg
+    proj = np.asarray(stack).max(0)
+    well, shrunken = wmg.make_well_mask(resize_aa(handle, proj, out_hw), handle=handle, seed=seed)
+    return well, np.logical_not(shrunken)
 
 
 def stack_field(handle: Handle, stack: np.ndarray, ds_width=384, hessian="gaussian_derivatives") -> np.ndarray:
