@@ -96,3 +96,33 @@ def test_script_end_to_end(tmp_path, plain):
     assert (out_root / "A1_fs-2.tif").is_file()
     cz.main(cz.parse_zproj_args([str(in_root), str(out_root)]))                       # default method: max
     assert np.array_equal(np.array(Image.open(out_root / "B7_max.tif")), stacks["B7"].max(axis=0))
+
+
+def test_script_time_series_and_area(tmp_path, plain):
+    """--time N selects the T plane of an ImageJ hyperstack (reference helper.load_image), and -a/--area runs the cell-area drop-in on
+    the projections with OUT_ROOT as its input and output directory (compute_zproj.py:98-119)"""
+    import csv
+    import subprocess
+    from PIL import Image, TiffImagePlugin
+    from oracle import cellarea as ca
+    from tmat_amd import synth
+    script = REPO / "tissue-model-analysis-tools_amd" / "scripts" / "compute_zproj.py"
+    in_root, out_root = tmp_path / "in", tmp_path / "out"
+    in_root.mkdir()
+    T, Z = 2, 3
+    vol = np.stack([np.stack([synth.synth_image(50 + 10 * t + z, 256, n_vessels=10, scale=0.5) for z in range(Z)]) for t in range(T)])      # (T, Z, H, W)
+    ifd = TiffImagePlugin.ImageFileDirectory_v2()
+    ifd[270] = f"ImageJ=1.53\nimages={T * Z}\nslices={Z}\nframes={T}\nhyperstack=true\n"
+    pages = [Image.fromarray(vol[t, z]) for t in range(T) for z in range(Z)]          # ImageJ order: Z runs faster than T
+    pages[0].save(in_root / "plate.tif", save_all=True, append_images=pages[1:], tiffinfo=ifd)
+    r = subprocess.run([sys.executable, str(script), str(in_root), str(out_root)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 1 and "time series image but no time index" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, str(script), str(in_root), str(out_root), "--time", "1", "-m", "max", "-a"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    proj = np.array(Image.open(out_root / "plate_max.tif"))
+    assert np.array_equal(proj, vol[1].max(axis=0))
+    rows = list(csv.reader(open(out_root / "calculations" / "cell_area.csv")))
+    assert rows[0] == ["image_id", "area_pct"] and rows[1][0] == "plate_max"
+    oa, ok = ca.cell_area(proj, 512, 0.0)
+    assert float(rows[1][1]) == oa * 100
+    assert np.array_equal(np.array(Image.open(out_root / "thresholded" / "plate_max_thresholded.png")), ok)

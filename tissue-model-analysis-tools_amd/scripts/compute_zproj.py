@@ -7,9 +7,12 @@ taken), same exit behaviour (message + exit code 1).
 
 IN_ROOT holds either multi-page image files (one stack per file) or slice images with a `z<number>` token in their
 names (directly, or one folder per stack).  The projections run in HIP kernels (csrc/zproj_kernels.hip) through
-tmat_zproj_batch; stacks of equal shape are projected together.  Differences: files are read with
-Pillow (TIFF / PNG; single channel unless --channel picks one of an interleaved image); time-series files (--time)
-and -a/--area (cell-area analysis after the projection) are outside the accelerated path and are refused.
+tmat_zproj_batch; stacks of equal shape are projected together.  Files are read with Pillow through tmat_amd.helper.load_image
+(the reference's helper.load_image contract: --time / --channel select the T / C plane of OME / ImageJ hyperstacks and must be
+given for time series / multi-channel files).  -a/--area runs the cell-area drop-in on the projections afterwards, with OUT_ROOT
+as its input and output directory, as the reference does (compute_zproj.py:98-119); the options that describe the input stacks
+(-m/--method, --time, --channel) are not forwarded to it (the reference forwards everything: its cell-area parser then rejects -m,
+and a forwarded --time / --channel fails on the single-plane projection files).
 """
 import argparse
 import os
@@ -71,22 +74,15 @@ def n_pages(path) -> int:
         return getattr(im, "n_frames", 1)
 
 
-def load_stack(path_or_paths, channel=None) -> np.ndarray:
-    """(Z, H, W) uint8 / uint16 stack from one multi-page file or from a list of slice files"""
-    if isinstance(path_or_paths, (list, tuple)):
-        pages = [pg for p in path_or_paths for pg in _pages(p)]
-    else:
-        pages = _pages(path_or_paths)
-    sl = []
-    for a in pages:
-        if a.ndim == 3:
-            if channel is None:
-                raise ValueError("multi-channel image but no --channel was specified")
-            a = a[..., channel] if a.shape[-1] <= 4 else a[channel]
-        if a.ndim != 2:
-            raise ValueError(f"expected 2-D slices, got shape {a.shape}")
-        sl.append(a)
-    st = np.stack(sl)
+def load_stack(path_or_paths, channel=None, time=None) -> np.ndarray:
+    """(Z, H, W) uint8 / uint16 stack from one multi-page file or from a list of slice files (reference helper.load_image)"""
+    from tmat_amd import helper
+    st, _ = helper.load_image(list(path_or_paths) if isinstance(path_or_paths, (list, tuple)) else path_or_paths, time, channel)
+    st = np.asarray(st)
+    if st.ndim == 2:
+        st = st[None]
+    if st.ndim != 3:
+        raise ValueError(f"expected a Z stack of 2-D slices, got shape {st.shape}")
     if st.dtype not in (np.uint8, np.uint16):
         raise ValueError(f"expected uint8/uint16 pixels, got {st.dtype}")
     return st
@@ -100,14 +96,13 @@ def save_projection(path, img):
 
 
 def main(args=None):
-    if args is None:
-        args = parse_zproj_args()
-    if getattr(args, "area", False):
-        print(f"{FAIL} -a/--area (cell area after the projection) is not part of the accelerated path.", flush=True)
-        sys.exit(1)
-    if getattr(args, "time", None) is not None:
-        print(f"{FAIL} --time: time-series files are not part of the accelerated path.", flush=True)
-        sys.exit(1)
+    args_prespecified = args is not None and not isinstance(args, list)
+    if args is None or isinstance(args, list):
+        argv = sys.argv[1:] if args is None else list(args)
+        args = parse_zproj_args(argv)
+    else:
+        argv = []
+    compute_area_after_zproj = bool(getattr(args, "area", False))
     in_root = args.in_root
     if not os.path.isdir(in_root):
         print(f"{FAIL} Input data directory not found:{os.linesep}\t{in_root}", flush=True)
@@ -170,7 +165,7 @@ def main(args=None):
     for zs_id, zs_path in zstack_paths.items():
         print(f"Processing {zs_id}...", flush=True)
         try:
-            st = load_stack(zs_path, args.channel)
+            st = load_stack(zs_path, args.channel, getattr(args, "time", None))
         except (OSError, ValueError) as error:
             print(f"{FAIL}{error}", flush=True)
             sys.exit(1)
@@ -182,6 +177,26 @@ def main(args=None):
     flush(groups)
     print("... Projections saved.", flush=True)
     print(OK, flush=True)
+
+    if compute_area_after_zproj:
+        # compute_zproj.py:98-119: the cell-area tool on the projections, OUT_ROOT as both its input and its output directory
+        import subprocess
+        options, skip = [], False
+        for arg in argv:
+            if skip:
+                skip = False
+                continue
+            if arg in ("-a", "--area", args.in_root, args.out_root):
+                continue
+            # options that describe the INPUT stacks: the projections written above are single-plane files
+            if arg in ("-m", "--method", "--time", "--channel"):
+                skip = True
+                continue
+            if arg.startswith(("--method=", "--time=", "--channel=")) or (arg.startswith("-m") and len(arg) > 2 and not arg.startswith("--")):
+                continue
+            options.append(arg)
+        script_path = Path(__file__).resolve().parent / "compute_cell_area.py"
+        subprocess.run([sys.executable, str(script_path), *options, str(out_root), str(out_root)], check=True)
 
 
 if __name__ == "__main__":
