@@ -3,12 +3,12 @@
 same positional arguments, flags and config keys, same outputs (`thresholded/<id>_thresholded.png`,
 `calculations/cell_area.csv` with columns image_id, area_pct; -2, -3 ... when a name is taken), same exit behaviour.
 
-    python compute_cell_area.py IN_ROOT OUT_ROOT [--channel N] [--time N] [--sd-coef F] [-c CONFIG]
+    python compute_cell_area.py IN_ROOT OUT_ROOT [--channel N] [--time N] [--sd-coef F] [-c CONFIG] [-w [--well-seed N]]
 
 Z stacks (slice sequences or multi-page files) are max-projected first, as in the reference.  Differences
 (INTEGRATION.md): images are thresholded in batches on the GPU (tmat_cell_area_batch); the gaussian-mixture fit is
-deterministic, so `rs_seed` has no effect; -w/--detect-well (an unseeded random search in the reference) and --time other
-than 0 are refused; files are read and written with Pillow.
+deterministic, so `rs_seed` has no effect; -w/--detect-well takes an explicit --well-seed (the reference's superellipse search is
+unseeded); --time / --channel follow the reference's helper.load_image; files are read and written with Pillow.
 """
 import argparse
 import csv

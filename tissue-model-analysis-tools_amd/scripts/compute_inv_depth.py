@@ -8,7 +8,7 @@ Probability, Invasion Prediction (0=no 1=yes); -2, -3 ... when the name is taken
 The n_pred_models classifiers with the lowest fine-tuning validation loss (model_training/best_ensemble/best_model_history_*.csv)
 are loaded from `best_finetune_weights_{i}.tmatw` (Keras `.h5` files converted once with tools/convert_keras_h5.py --resnet;
 TMAT_SYNTHETIC_WEIGHTS=1 runs random-init weights of the same architecture) and run on the GPU through tmat_inv_depth_predict.
-Differences: files are read with Pillow; --time other than 0 is refused.
+Differences: files are read with Pillow (--time / --channel follow the reference's helper.load_image).
 """
 import argparse
 import csv
