@@ -55,6 +55,20 @@ def main():
                                            "hessian": a.hessian},
            "stages_ms": {"stack_prepare": (t2 - t1) * 1e3, "vessel_field": (t3 - t2) * 1e3, "field_stats": (t4 - t3) * 1e3},
            "rows": [list(r) for r in rows[-2:]]}
+    # roofline of the stage that holds the branch's arithmetic: scipy-exact separable correlations of the Sato Hessian, f64 accumulation
+    # (two adds + one multiply per tap pair, no contraction): 10 passes per sigma, radius r(sigma) tap pairs per pixel and pass
+    import math
+    if a.hessian == "gaussian_derivatives":
+        radii = [int((100.0 if sg <= 1 else 8.0) * sg / math.sqrt(2) + 0.5) for sg in sato.SATO_SIGMAS]
+        pairs_px = 10 * sum(radii)
+    else:
+        pairs_px = 2 * sum(int(4.0 * sg + 0.5) for sg in sato.SATO_SIGMAS)        # gaussian smoothing only; the gradients are differences
+    pairs = float(pairs_px) * field.shape[0] * field.shape[1] * (a.slices - 1)
+    F64_PAIR_PEAK = 39.3e12 / 3.0        # MI355X f64 vector rate (lane-ops/s) over the 3 operations of a tap pair
+    out["roofline"] = {"bound": "f64 vector ALU", "achieved": pairs / (t3 - t2) / 1e12, "peak": F64_PAIR_PEAK / 1e12, "unit": "10^12 tap pairs/s",
+                       "frac": pairs / (t3 - t2) / F64_PAIR_PEAK, "traffic": None, "kernel": "tmat::corr1d_col_kernel / corr1d_row_kernel (Sato Hessian)",
+                       "note": f"{pairs_px} tap pairs per pixel and slice pair over the WHOLE vessel_field call (upload of the prepared volume, unsharp, "
+                               "canny, medial axis, region growing and mask filter inside the time); per kernel: profiles/*_stack_kernel_stats.csv"}
     if not a.no_cpu:
         from oracle import sato as osato
         c0 = time.perf_counter()

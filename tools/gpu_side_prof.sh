@@ -27,7 +27,7 @@ for r in csv.DictReader(open(sys.argv[1])):
         cnt[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
 dur = {r["Dispatch_Id"]: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(sys.argv[2])) if "zproj_focus" in r["Kernel_Name"]}
 for k, v in sorted(cnt.items(), key=lambda kv: int(kv[0]))[-1:]:
-    print(f"zproj_focus_kernel, 8 stacks of 16 x 2048 x 2048 u16, one launch of {dur.get(k, 0):.1f} us: " + ", ".join(f"{c} {x:.6g}" for c, x in sorted(v.items())))
+    print(f"zproj_focus_kernel, 16 x 2048 x 2048 u16 stacks (one stack per launch), last launch of {dur.get(k, 0):.1f} us: " + ", ".join(f"{c} {x:.6g}" for c, x in sorted(v.items())))
 PY
   rm -rf $OUT/zp_$tag
 done
