@@ -76,7 +76,7 @@ template <int BM, int BN, int WM, int WN, int KS, bool RELU, int PREC = 0>
 #ifndef TMAT_CONV_WPS
 #define TMAT_CONV_WPS 4     // waves per SIMD the 8-wave conv kernel is compiled for (VGPR budget 512 / this)
 #endif
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 > 65536 ? 2 : WM * WN == 8 ? TMAT_CONV_WPS : 2)) void conv_mfma_kernel(ConvArgs a, int M, int Ho, int Wo, int nMt, int nNt, FastDiv dHW, FastDiv dW)
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 > 65536 ? 2 : WM * WN == 8 ? TMAT_CONV_WPS : 2)) void conv_mfma_kernel(ConvArgs a, int M, int Ho, int Wo, int nMt, int nNt, FastDiv dHW, FastDiv dW, int nstat)
 {
     // KS (1, 2 or 3) is a template parameter so that the 3x3 and the pointwise instantiations are distinct kernels
     // (distinct names in rocprofv3 traces: the 3x3 <128,128,2,2,3,*> instantiations are the dominant kernel).
@@ -108,14 +108,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
     // nNt column tiles of one pixel tile to the same XCD so its L2 serves the re-read A pixels.
     const int b = blockIdx.x;
     const int xcd = b & 7, j = b >> 3;
-#ifdef TMAT_VAR_NMAP      // experiment: an XCD keeps ONE column tile's weights (L2-resident) and shares the pixel tiles with 8 / nNt - 1 others
-    const bool nstat = nNt > 1 && nNt <= 8 && (8 % nNt) == 0;
+    // Two mappings.  Default: the nNt column tiles of one pixel tile go to the same XCD (its L2 serves the re-read A pixels; every XCD
+    // streams ALL weights).  N-stationary (nstat, chosen by the host when the layer's weights exceed what an XCD's 4 MB L2 keeps, i.e.
+    // the 512 -> 512 3x3 layers: 9.4 MB): XCD x keeps column tile x % nNt -- 2.4 MB of weights, L2-resident -- and shares the pixel
+    // tiles with the 8 / nNt - 1 other XCDs of its group; A is then fetched nNt times from the fabric.  Measured (FETCH_SIZE as
+    // read, per launch of 1600 patches, 1.31 GB of input): 512 -> 512 at 20 x 20: 15.7 GB default (6.5 in another run: the weight
+    // stream thrashes the L2 differently from run to run), 5.0 GB N-stationary; 256 -> 256 at 40 x 40 (2.4 MB of weights): 3.9 GB
+    // default, 5.3 GB N-stationary.  The launch times do not differ (the pipeline hides the latency either way).
     const int nt = nstat ? xcd % nNt : j % nNt;
     const int mt = nstat ? j * (8 / nNt) + xcd / nNt : (j / nNt) * 8 + xcd;
-#else
-    const int nt = j % nNt;
-    const int mt = (j / nNt) * 8 + xcd;
-#endif
     if (mt >= nMt) return;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -513,24 +514,26 @@ static void launch_conv_ks(const ConvArgs &a, int M, int Ho, int Wo, hipStream_t
     int nMt = (M + BM - 1) / BM, nNt = a.Cout / BN;
     dim3 grid(((nMt + 7) / 8) * 8 * nNt, KS == 2 ? 4 : 1);
     const FastDiv dHW = make_fastdiv(Ho * Wo), dW = make_fastdiv(Wo);
+    // N-stationary block mapping (see the kernel) for layers whose weights do not stay in an XCD's L2
+    const int nstat = (nNt > 1 && nNt <= 8 && 8 % nNt == 0 && (size_t)(KS == 2 ? 4 : KS * KS) * a.Cin * a.Cout * 4 > ((size_t)3 << 20)) ? 1 : 0;
     if (a.prec == 1) {
         if (a.relu_in)
-            hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, true, 1>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt, dHW, dW);
+            hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, true, 1>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt, dHW, dW, nstat);
         else
-            hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, false, 1>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt, dHW, dW);
+            hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, false, 1>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt, dHW, dW, nstat);
         return;
     }
     if (a.prec == 2) {
         if (a.relu_in)
-            hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, true, 2>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt, dHW, dW);
+            hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, true, 2>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt, dHW, dW, nstat);
         else
-            hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, false, 2>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt, dHW, dW);
+            hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, false, 2>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt, dHW, dW, nstat);
         return;
     }
     if (a.relu_in)
-        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, true>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt, dHW, dW);
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, true>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt, dHW, dW, nstat);
     else
-        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, false>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt, dHW, dW);
+        hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, false>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt, dHW, dW, nstat);
 }
 
 template <int BM, int BN, int WM, int WN>

@@ -13,6 +13,8 @@ timeout -k 10 600 bash tools/gpu_stack_prof.sh > $OUT/stack.log 2>&1
 cp gpurun_out/stack_prof/bench.json $OUT/stack_bench.json 2>/dev/null
 cp gpurun_out/stack_prof/kernel_stats.csv $OUT/stack_kernel_stats.csv 2>/dev/null
 timeout -k 10 300 python3 tools/bench_zproj.py --stacks 32 --steps 5 > $OUT/zproj_bench.json 2> $OUT/zproj.err
+# BASELINE config #3 end to end: focus stacking, then the 2-D branch on the 2048 x 2048 projections (first line of the output)
+timeout -k 10 400 python3 tools/bench_zproj.py --chain --stacks 8 --steps 1 --warmup 1 2> $OUT/chain.err | head -1 > $OUT/config3_chain.json
 cd /tmp && export TMPDIR=/tmp
 for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
   tag=$(echo $grp | cut -d' ' -f1)
