@@ -179,10 +179,19 @@ def main():
     # pixels on the CPU, the process group is gloo, and everything AROUND the hot path (sharding, barriers, the max-over-ranks
     # of the elapsed time, the row all-gather, the JSON line) runs exactly as it does on GPUs.  Its number is not a measurement.
     stub = os.environ.get("TMAT_BENCH_STUB") == "1"
+    # TMAT_BENCH_REHEARSE=1 (tests/test_gpu_bench_rehearsal.py): the real handles and kernels under N > 1 ranks on a box with FEWER GPUs than
+    # ranks -- rank r uses device r % device_count and the collectives run over gloo (RCCL refuses two ranks on one device).  Everything
+    # but the transport of the two collectives is what an N-GPU run executes; its number is not a measurement and the line says so.
+    rehearse = os.environ.get("TMAT_BENCH_REHEARSE") == "1" and not stub
+    dev_index = local_rank
     dist = None
     if world > 1:
         import torch.distributed as dist
         if stub:
+            dist.init_process_group("gloo")
+        elif rehearse:
+            dev_index = local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(dev_index)
             dist.init_process_group("gloo")
         else:
             torch.cuda.set_device(local_rank)
@@ -204,7 +213,7 @@ def main():
     else:
         from tmat_amd import _lib
         weights = synth.synth_weights(0)
-        handle = _lib.Handle(synth.pack_weights(weights), local_rank, args.max_patches)
+        handle = _lib.Handle(synth.pack_weights(weights), dev_index, args.max_patches)
         L = _lib.lib()
         # resident in HBM before the timed region (each rank has its own images)
         dptr = ctypes.c_void_p()
@@ -258,7 +267,7 @@ def main():
             raise SystemExit(f"bench: image {i} and its copy {i % nd} produced different rows: {r} vs {rows[i % nd]}")
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if stub else "cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if (stub or rehearse) else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # the one collective of the path: a single fixed-size all-gather of the 32-byte result rows over RCCL/xGMI
@@ -361,6 +370,8 @@ def main():
         out["cpu_baseline"] = None
     if rank == 0 and stub:
         out["data"] = "synthetic (TMAT_BENCH_STUB: stand-in analyser on the CPU, not a measurement)"
+    if rank == 0 and rehearse:
+        out["data"] = f"synthetic (TMAT_BENCH_REHEARSE: {world} ranks share {torch.cuda.device_count()} GPU(s), collectives over gloo -- not a measurement)"
 
     if not stub:
         _lib.check(L.tmat_dev_free(handle.raw, dptr), "dev_free")
