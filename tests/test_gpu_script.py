@@ -54,6 +54,31 @@ def test_script_end_to_end(tmp_path, handle):
     assert read_csv(outd / "branching_analysis_CONFIG_thresh1_5.0.csv")[1:] == rows[1:]
 
 
+def test_script_two_ranks_on_one_gpu_write_the_one_process_csv(tmp_path):
+    """the script's N > 1 flow with the real library (TMAT_DIST_REHEARSE=1: both ranks on device 0, the row gather over gloo because RCCL
+    refuses two ranks on one device): 5 images -- an uneven split -- sharded, analysed, gathered, written by rank 0; the CSV equals the
+    one-process CSV byte for byte"""
+    import socket
+    from tmat_amd import synth
+    ind = tmp_path / "in"
+    ind.mkdir()
+    for i in range(5):
+        np.save(ind / f"img_{i}.npy", synth.synth_image(60 + i, 512, n_vessels=12, scale=1.0))
+    r = run([str(ind), str(tmp_path / "w1"), "--image-width-microns", "500"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ, TMAT_SYNTHETIC_WEIGHTS="1", TMAT_DIST_REHEARSE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(SCRIPT), str(ind), str(tmp_path / "w2"), "--image-width-microns", "500"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    a = (tmp_path / "w1" / "branching_analysis.csv").read_bytes()
+    b = (tmp_path / "w2" / "branching_analysis.csv").read_bytes()
+    assert a == b and len(read_csv(tmp_path / "w2" / "branching_analysis.csv")) == 6
+
+
 def test_script_error_exits(tmp_path):
     r = run([str(tmp_path / "missing"), str(tmp_path / "o")])
     assert r.returncode == 1 and "does not exist" in r.stdout

@@ -322,16 +322,10 @@ def main(args=None):
     # image_width_microns: the option / config key, else per image from the file's metadata (reference
     # compute_branches.py:184-212: img.shape[-1] * PhysicalPixelSizes.X), else the reference's failure message
     from tmat_amd import branches, distributed, helper, models
-    ws, rank, local_rank = distributed.world()
+    ws = distributed.world()[0]
     # host stages (thinning, DMT, MorseGraph) run on worker threads of every rank: share the cores between the ranks
     os.environ.setdefault("TMAT_HOST_THREADS", str(distributed.host_threads_per_rank(ws)))
-    if ws > 1:
-        import torch
-        import torch.distributed as dist
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend)
+    ws, rank, local_rank = distributed.init_process_group_from_env()
     if is_stack:
         run_stacks(args, config, paths, out_root, rank, ws, local_rank)
         return

@@ -78,15 +78,20 @@ def gather_rows(rows_local, n_total=None, device=None, failed=False):
 
 
 def init_process_group_from_env():
-    """(world_size, rank, local_rank); under torch.distributed.run the process group is created (nccl = RCCL when a GPU is
-    visible, gloo otherwise) and this rank's device selected"""
+    """(world_size, rank, device index); under torch.distributed.run the process group is created (nccl = RCCL when a GPU is
+    visible, gloo otherwise) and this rank's device selected.
+    TMAT_DIST_REHEARSE=1 (tests): more ranks than GPUs -- rank r uses device local_rank % device_count and the collectives run over
+    gloo (RCCL refuses two ranks on one device); the scripts' whole multi-rank flow then runs on a one-GPU box with the real library."""
     ws, rank, local_rank = world()
     if ws > 1:
         import torch
         import torch.distributed as dist
+        rehearse = os.environ.get("TMAT_DIST_REHEARSE") == "1" and torch.cuda.is_available()
+        if rehearse:
+            local_rank = local_rank % max(1, torch.cuda.device_count())
         if not dist.is_initialized():
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-            if backend == "nccl":
+            backend = "nccl" if (torch.cuda.is_available() and not rehearse) else "gloo"
+            if torch.cuda.is_available():
                 torch.cuda.set_device(local_rank)
             dist.init_process_group(backend)
     return ws, rank, local_rank
