@@ -382,14 +382,33 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
         for (int jn = 0; jn < 4; jn++) {
             const float sc = scv[jn], sh = shv[jn];
             float v[16];
+            if (a.relu_out) {             // uniform branch: the network's pooled layers have no ReLU, and a max per value is matrix time
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                v[e] = fmaxf(fmaf(acc[jn][e], sc, sh), relu_lo);
-                acc[jn][e] = 0.f;
+                for (int e = 0; e < 16; e++) v[e] = fmaxf(fmaf(acc[jn][e], sc, sh), 0.f);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; e++) v[e] = fmaf(acc[jn][e], sc, sh);
             }
-            // columns 8 h + k, k = 0..7: own register 8 h + k; the other half wave's register of the same index holds the other
-            // tile row.  (v_permlane32_swap_b32 would do the exchange in one vector instruction; with this register reuse pattern
-            // the ROCm 7.2 builtin produced wrong values although tools/dev/permlane_probe.hip shows the documented semantics.)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[jn][e] = 0.f;
+            // columns 8 h + k, k = 0..7: own register 8 h + k; the other half wave's register of the same index holds the other tile
+            // row.  v_permlane32_swap_b32 A, B exchanges A's upper half wave with B's lower one: with A = v[k], B = v[8 + k] a lane of
+            // half 0 then holds (own v[k], the other half's v[k]) and a lane of half 1 (the other half's v[8 + k], own v[8 + k]) -- both rows
+            // of its column in (A, B), one vector instruction instead of two selects and a ds_bpermute.  Inline assembly: the ROCm 7.2
+            // builtin returned wrong values in this register pattern (tools/dev/permlane_probe.hip checks this form against the shuffles).
+#ifndef WS_POOL_SHUFFLE
+            const float v8 = v[8], o8 = __shfl_xor(v8, 32);      // column 8 (half 0 only): taken before the swaps
+            float y0[9], m01[9];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                float A = v[k], B = v[8 + k];
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(A), "+v"(B));
+                m01[k] = fmaxf(A, B);
+                y0[k] = ((h != 0) != (k >= 4)) ? B : A;          // tile row 2 w: own for quads 0, 2 of the half, the other's for quads 1, 3
+            }
+            y0[8] = h ? NEG : o8;       // column 8 h + 8: x = 8 for h = 0 (register 8: this half holds its y1, the other half its y0), none for h = 1
+            m01[8] = h ? NEG : fmaxf(o8, v8);
+#else
             float y0[9], y1[9];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
@@ -403,9 +422,11 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
                 y0[8] = h ? NEG : o8;
                 y1[8] = h ? NEG : v[8];
             }
-            float m01[9], h0[4];
+            float m01[9];
 #pragma unroll
             for (int k = 0; k < 9; k++) m01[k] = fmaxf(y0[k], y1[k]);
+#endif
+            float h0[4];
 #pragma unroll
             for (int qq = 0; qq < 4; qq++) {
                 hm[jn][qq] = fmaxf(fmaxf(m01[2 * qq], m01[2 * qq + 1]), m01[2 * qq + 2]);
