@@ -66,8 +66,8 @@ __device__ long long ws_diag[256 * 12 * 8];
 #define WS_STAMP(k) { const long long now_ = (long long)__builtin_readcyclecounter(); dsum[k] += now_ - dlast; dlast = now_; }
 #define WS_DIAG_DECL long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dlast = (long long)__builtin_readcyclecounter();
 #define WS_DIAG_FLUSH() if (lane == 0 && blockIdx.x < 256) { for (int k = 0; k < 8; k++) ws_diag[((size_t)blockIdx.x * 12 + wave) * 8 + k] = dsum[k]; }
-__device__ long long ws_tl[12 * 2 * 10];         // absolute stamps of workgroup 0's waves in steps 9 (mid tile) and 11 (tile end)
-#define WS_TL(k) if (lane == 0 && blockIdx.x == 0 && (s == 9 || s == 11)) ws_tl[(wave * 2 + (s == 11)) * 10 + (k)] = (long long)__builtin_readcyclecounter();
+__device__ long long ws_tl[12 * 2 * 14];         // absolute stamps of workgroup 0's waves in steps 13 (mid tile) and 15 (tile end)
+#define WS_TL(k) if (lane == 0 && blockIdx.x == 0 && (s == 13 || s == 15)) ws_tl[(wave * 2 + (s == 15)) * 14 + (k)] = (long long)__builtin_readcyclecounter();
 #else
 #define WS_TL(k)
 #define WS_STAMP(k)
@@ -364,7 +364,11 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
 
     // ---- POOL epilogue (see sepconv_kernels.hip:store_tile_pool for the derivation): MaxPooling2D(3, 2, "same") of the
     // tile from the accumulators; row 2w + 2 comes from wave w + 1 through the exchange buffer
+    int tl_s = -1;          // step index for the WS_DIAG timeline stamps inside the epilogue
     auto store_tile_pool = [&](int jj, float *xch) {
+#ifdef WS_DIAG
+        const int s = tl_s;
+#endif
         constexpr int NW = 8, XC = 128;
         const int mt = jj / nNt, nt = jj - mt * nNt;
         const int n = mt / TPP, tr = mt - n * TPP;
@@ -440,8 +444,11 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
                 if (wave == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y0[0]), rsCO, r * 4, jn * 128, 0);
             }
         }
+        WS_TL(9)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        WS_TL(10)
         WS_BAR()
+        WS_TL(11)
 #pragma unroll
         for (int jn = 0; jn < 4; jn++) {
 #pragma unroll
@@ -460,6 +467,7 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // exchange values read before the step's closing barrier
+        WS_TL(12)
     };
 
     WS_DIAG_DECL
@@ -491,8 +499,11 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
     for (int s = 0; s < total; s++) {
         const int stage = s & 1;
         WS_STAMP(0)
-        if (cc == 0) load_scale_shift(cj);
-        if (POOL && cc == nchunks - 1) load_resid(cj);
+        // (scale / shift of a tile and the residual values of its pooled pixels are requested in the vector phase BEFORE the step that
+        // needs them: at the top of a step the producers have just queued their 26 LDS-DMA / buffer loads, and a consumer's 16 residual
+        // loads behind them held its first MFMA back by ~3 300 cycles -- WS_DIAG timeline, tile-end step)
+        if (s == 0) load_scale_shift(cj);
+        if (POOL && nchunks == 1) load_resid(cj);
         const float *As = smem + (stage ? WS_A1 : WS_A0) + aoffc;
         const float *Bs = smem + (stage ? WS_B1 : WS_B0) + boffc;
         WS_TL(0)
@@ -528,9 +539,15 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
         WS_TL(6)
         if (++cc == nchunks) {
             cc = 0;
+            tl_s = s;
             if (POOL) store_tile_pool(cj, smem + (stage ? WS_A : 0));
             else store_tile(cj, smem + (stage ? WS_A1 : WS_A0) + wave * 1024);
             cj++;
+        }
+        WS_PIN()
+        if (s + 1 < total) {
+            if (cc == 0) load_scale_shift(cj);                                   // the next step starts tile cj
+            if (POOL && nchunks > 1 && cc == nchunks - 1) load_resid(cj);       // the next step ends tile cj
         }
         WS_PIN()
         if (s + 1 < total) {
@@ -593,14 +610,14 @@ static void launch_ws_any(const WsArgs &a, int relu_in, hipStream_t s)
         fprintf(stderr, "[wsdiag] H %d Cin %d Cout %d pool %d | consumer per step: top %.0f mfma %.0f barX %.0f epilogue %.0f barY %.0f | producer per step: issue %.0f vmcnt0 %.0f rows %.0f barX %.0f compute %.0f barY %.0f | steps/wave %.0f\n",
                 a.H, a.Cin, a.Cout, (int)POOL, cs[0] / cst, cs[1] / cst, cs[2] / cst, cs[3] / cst, cs[4] / cst,
                 ps[0] / pst, ps[1] / pst, ps[2] / pst, (ps[3] + ps[4]) / pst, ps[5] / pst, ps[6] / pst, cst / (nb * 8.0));
-        static long long tl[12 * 2 * 10];
+        static long long tl[12 * 2 * 14];
         hipMemcpyFromSymbol(tl, HIP_SYMBOL(ws_tl), sizeof(tl));
         for (int st = 0; st < 2; st++) {
-            long long t0 = tl[st * 10];
-            for (int w = 0; w < 12; w++) if (tl[(w * 2 + st) * 10] < t0) t0 = tl[(w * 2 + st) * 10];
+            long long t0 = tl[st * 14];
+            for (int w = 0; w < 12; w++) if (tl[(w * 2 + st) * 14] < t0) t0 = tl[(w * 2 + st) * 14];
             for (int w = 0; w < 12; w++) {
-                fprintf(stderr, "[wstl] step %d wave %2d:", st ? 11 : 9, w);
-                for (int k = 0; k < (w < 8 ? 9 : 5); k++) fprintf(stderr, " %6lld", tl[(w * 2 + st) * 10 + k] - t0);
+                fprintf(stderr, "[wstl] step %d wave %2d:", st ? 15 : 13, w);
+                for (int k = 0; k < (w < 8 ? 13 : 5); k++) fprintf(stderr, " %6lld", tl[(w * 2 + st) * 14 + k] - t0);
                 fprintf(stderr, "\n");
             }
         }
