@@ -293,8 +293,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
             _Pragma("unroll") for (int i = 0; i < TM; i++) av[g][i] = *reinterpret_cast<const float4 *>((stage_) + arow + i * 32 * KC + slot); \
             _Pragma("unroll") for (int jn = 0; jn < TN; jn++) bv[g][jn] = *reinterpret_cast<const float4 *>((stage_) + brow + jn * 32 * KC + slot); \
         }
-#define TMAT_MFMAS()                                                                   \
-        _Pragma("unroll") for (int g = 0; g < 4; g++) {                                \
+#define TMAT_MFMAS() TMAT_MFMAS_RANGE(0, 4)
+#define TMAT_MFMAS_RANGE(G0, G1)                                                       \
+        _Pragma("unroll") for (int g = (G0); g < (G1); g++) {                          \
             if (RELU) {                                                                \
                 _Pragma("unroll") for (int i = 0; i < TM; i++) {                       \
                     av[g][i].x = TMAT_RELU(av[g][i].x); av[g][i].y = TMAT_RELU(av[g][i].y); \
@@ -321,15 +322,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
         TMAT_LOOP_SYNC()                                                               \
     }
 #else
+// The next chunk's LDS-DMA is issued BEHIND the first k group's MFMAs (TMAT_DMA_AFTER = 1): after a barrier all eight waves of a
+// workgroup are at the same point, and with the DMA issue (4 instructions + ~30 scalar ones per wave) in front of the MFMAs the matrix
+// pipe waited for it unless the other workgroup of the CU happened to be in its MFMA stretch.  Measured per pass of 1600 patches: DMA
+// first 255.3 ms, after group 0: 252.1, after group 1: 252.0, after group 2: 254.1 (the DMA then lands late for the chunk's closing wait).
+#ifndef TMAT_DMA_AFTER
+#define TMAT_DMA_AFTER 1
+#endif
 #define TMAT_STEP(cur, nxt, more)                                                      \
     {                                                                                  \
         float4 av[4][TM], bv[4][TN];                                                   \
         TMAT_READ_FRAGS(cur)                                                           \
         TMAT_PIN()                                                                     \
+        TMAT_PRIO(1)                                                                   \
+        TMAT_MFMAS_RANGE(0, TMAT_DMA_AFTER)                                            \
+        TMAT_PIN()                                                                     \
         if (more) TMAT_LOOP_ISSUE(nxt)                                                 \
         TMAT_PIN()                                                                     \
-        TMAT_PRIO(1)                                                                   \
-        TMAT_MFMAS()                                                                   \
+        TMAT_MFMAS_RANGE(TMAT_DMA_AFTER, 4)                                            \
         TMAT_PRIO(0)                                                                   \
         TMAT_PIN()                                                                     \
         TMAT_LOOP_SYNC()                                                               \
@@ -357,9 +367,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
                 _Pragma("unroll") for (int jn = 0; jn < TN; jn++)                      \
                     bp[tk][pl][jn] = *reinterpret_cast<const bf16x8 *>((cur) + browp + pl * BN * 16 + jn * 32 * 16 + (((2 * tk + hi) ^ keyb) * 4)); \
         TMAT_PIN()                                                                     \
-        if (more) TMAT_LOOP_ISSUE(nxt)                                                 \
+        /* the next chunk's DMA: six products -- behind the first k step's MFMAs, as in the f32 step (209.8 -> 204.3 ms per pass); three */ \
+        /* products -- in front (a chunk is only 384 cycles of matrix time per wave: issued later, the DMA lands late: +4 ms per pass) */ \
+        if (NPL == 2) { if (more) TMAT_LOOP_ISSUE(nxt) }                               \
         TMAT_PIN()                                                                     \
         _Pragma("unroll") for (int tk = 0; tk < 2; tk++) {                             \
+            if (NPL == 3 && tk == 1) {                                                 \
+                TMAT_PIN()                                                             \
+                if (more) TMAT_LOOP_ISSUE(nxt)                                         \
+                TMAT_PIN()                                                             \
+            }                                                                          \
             if (NPL == 3 && tk == 1) {                                                 \
                 _Pragma("unroll") for (int pl = 0; pl < NPL; pl++)                     \
                     _Pragma("unroll") for (int jn = 0; jn < TN; jn++)                  \
@@ -416,6 +433,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
 #undef TMAT_STEP
 #undef TMAT_READ_FRAGS
 #undef TMAT_MFMAS
+#undef TMAT_MFMAS_RANGE
 #undef TMAT_PIN
 #undef TMAT_PRIO
 #undef TMAT_LOOP_ISSUE
