@@ -260,11 +260,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
     // ReLU on a fragment register: as a signed integer a negative float (and -0.0) is negative, so one v_max_i32 with 0
     // gives relu(x) = x > 0 ? x : +0.0 exactly (no NaNs here), without fmaxf's canonicalisation.
 #define TMAT_RELU(v) __builtin_bit_cast(float, max(__builtin_bit_cast(int, (v)), 0))
-    // One step = one K chunk: all 16 fragment reads of the chunk are issued up front (64 VGPRs), then the DMA of the
-    // next chunk into the other stage, then the 64 MFMAs, then the barrier (hipcc puts the DMA's vmcnt(0) in front of it).
-    // sched_barrier(0) pins that order: left alone, hipcc sinks the reads next to their MFMAs and hoists the barrier.
-    // (TMAT_ABL_* / TMAT_VAR_*: timing experiments of tools/gpu_variants.sh; ablations produce wrong results and nothing
-    // of this is defined in the shipped build.)
+    // One step = one K chunk: fragment reads, the DMA of the next chunk into the other stage and the chunk's MFMAs in the order given
+    // at TMAT_ORDER below, then the wave's vmcnt(0) and the barrier.  sched_barrier(0) pins that order: left alone, hipcc sinks the
+    // reads next to their MFMAs and hoists the barrier.
 #if defined(TMAT_VAR_SETPRIO)
 #define TMAT_PRIO(x) __builtin_amdgcn_s_setprio(x);
 #else
@@ -287,8 +285,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
 // barrier, and must not depend on what hipcc chooses to put in front of a barrier), then the workgroup barrier
 #define TMAT_LOOP_SYNC() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
 #endif
-#define TMAT_READ_FRAGS(stage_)                                                        \
-        _Pragma("unroll") for (int g = 0; g < 4; g++) {                                \
+#define TMAT_READ_FRAGS(stage_) TMAT_READ_FRAGS_RANGE(stage_, 0, 4)
+#define TMAT_READ_FRAGS_RANGE(stage_, G0, G1)                                          \
+        _Pragma("unroll") for (int g = (G0); g < (G1); g++) {                          \
             const int slot = ((2 * g + hi) ^ key) * 4;                                 \
             _Pragma("unroll") for (int i = 0; i < TM; i++) av[g][i] = *reinterpret_cast<const float4 *>((stage_) + arow + i * 32 * KC + slot); \
             _Pragma("unroll") for (int jn = 0; jn < TN; jn++) bv[g][jn] = *reinterpret_cast<const float4 *>((stage_) + brow + jn * 32 * KC + slot); \
@@ -310,41 +309,34 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
                     acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g][i].w, bv[g][jn].w, acc[i][jn], 0, 0, 0); \
                 }                                                                      \
         }
-#if defined(TMAT_VAR_ISSUEFIRST)
-#define TMAT_STEP(cur, nxt, more)                                                      \
-    {                                                                                  \
-        float4 av[4][TM], bv[4][TN];                                                   \
-        if (more) TMAT_LOOP_ISSUE(nxt)                                                 \
-        TMAT_READ_FRAGS(cur)                                                           \
-        TMAT_PIN()                                                                     \
-        TMAT_MFMAS()                                                                   \
-        TMAT_PIN()                                                                     \
-        TMAT_LOOP_SYNC()                                                               \
-    }
+// Order of one step (R = the fragment reads of a k group: TM + TN ds_read_b128, M = its 8 TM TN MFMAs, D = the LDS-DMA of the next chunk):
+//     R0 R1 M0 R2 D M1 R3 M2 M3      then the wave's vmcnt(0) and the workgroup barrier.
+// After a barrier all eight waves of a workgroup stand at the same instruction, so whatever comes first is what the matrix pipe waits
+// for unless the CU's other workgroup happens to be in its MFMA stretch.  Round 1-2 issued all sixteen reads, then the DMA (4 instructions
+// + ~30 scalar ones per wave), then the 32 MFMAs: the first MFMA of the LAST wave waited for 8 x 16 KB of reads to drain through the LDS
+// pipe and for its own DMA issue.  Reads two groups ahead and the DMA behind the first group (measured per pass of 1600 patches):
+// 255.3 ms (old order) -> 252.1 (DMA behind M0) -> 248.2 (split reads); the orders R0 R1 M0 D R2 ..., R0 M0 R1 D M1 R2 ... measure the
+// same, the DMA behind M1 or later is slower (it lands late for the closing wait).  Bit-exact: the MFMA order is unchanged.
+// (TMAT_ABL_* / TMAT_VAR_*: timing experiments of tools/gpu_variants.sh; ablations produce wrong results and nothing of this is defined
+// in the shipped build.)
+#define R_(c_, g) TMAT_READ_FRAGS_RANGE(c_, g, g + 1) TMAT_PIN()
+#define M_(g) TMAT_MFMAS_RANGE(g, g + 1) TMAT_PIN()
+#define D_(n_, m_) if (m_) TMAT_LOOP_ISSUE(n_) TMAT_PIN()
+#if defined(TMAT_VAR_ORDER) && TMAT_VAR_ORDER == 0       // the round-2 order
+#define TMAT_ORDER(c_, n_, m_) R_(c_, 0) R_(c_, 1) R_(c_, 2) R_(c_, 3) D_(n_, m_) M_(0) M_(1) M_(2) M_(3)
+#elif defined(TMAT_VAR_ORDER) && TMAT_VAR_ORDER == 2
+#define TMAT_ORDER(c_, n_, m_) R_(c_, 0) R_(c_, 1) M_(0) D_(n_, m_) R_(c_, 2) M_(1) R_(c_, 3) M_(2) M_(3)
+#elif defined(TMAT_VAR_ORDER) && TMAT_VAR_ORDER == 3
+#define TMAT_ORDER(c_, n_, m_) R_(c_, 0) M_(0) R_(c_, 1) D_(n_, m_) M_(1) R_(c_, 2) M_(2) R_(c_, 3) M_(3)
 #else
-// The next chunk's LDS-DMA is issued BEHIND the first k group's MFMAs (TMAT_DMA_AFTER = 1): after a barrier all eight waves of a
-// workgroup are at the same point, and with the DMA issue (4 instructions + ~30 scalar ones per wave) in front of the MFMAs the matrix
-// pipe waited for it unless the other workgroup of the CU happened to be in its MFMA stretch.  Measured per pass of 1600 patches: DMA
-// first 255.3 ms, after group 0: 252.1, after group 1: 252.0, after group 2: 254.1 (the DMA then lands late for the chunk's closing wait).
-#ifndef TMAT_DMA_AFTER
-#define TMAT_DMA_AFTER 1
+#define TMAT_ORDER(c_, n_, m_) R_(c_, 0) R_(c_, 1) M_(0) R_(c_, 2) D_(n_, m_) M_(1) R_(c_, 3) M_(2) M_(3)
 #endif
 #define TMAT_STEP(cur, nxt, more)                                                      \
     {                                                                                  \
         float4 av[4][TM], bv[4][TN];                                                   \
-        TMAT_READ_FRAGS(cur)                                                           \
-        TMAT_PIN()                                                                     \
-        TMAT_PRIO(1)                                                                   \
-        TMAT_MFMAS_RANGE(0, TMAT_DMA_AFTER)                                            \
-        TMAT_PIN()                                                                     \
-        if (more) TMAT_LOOP_ISSUE(nxt)                                                 \
-        TMAT_PIN()                                                                     \
-        TMAT_MFMAS_RANGE(TMAT_DMA_AFTER, 4)                                            \
-        TMAT_PRIO(0)                                                                   \
-        TMAT_PIN()                                                                     \
+        TMAT_ORDER(cur, nxt, more)                                                     \
         TMAT_LOOP_SYNC()                                                               \
     }
-#endif
 
     // split-precision step: k step tk (0, 1) of the chunk covers channels 16 tk .. 16 tk + 15; a lane's 8 values are channels
     // 16 tk + 8 h + j (A: 16-byte units 4 tk + 2 h, 4 tk + 2 h + 1 of its f32 row; B: unit 2 tk + h of its row in every plane)
@@ -431,7 +423,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
     }
 #undef TMAT_STEP_BF16
 #undef TMAT_STEP
+#undef TMAT_ORDER
+#undef R_
+#undef M_
+#undef D_
 #undef TMAT_READ_FRAGS
+#undef TMAT_READ_FRAGS_RANGE
 #undef TMAT_MFMAS
 #undef TMAT_MFMAS_RANGE
 #undef TMAT_PIN
