@@ -93,8 +93,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
     constexpr int NPL = PREC == 0 ? 0 : PREC + 1;                            // bf16 weight planes of the split-precision forms
     constexpr int NPLA = NPL > 0 ? NPL : 1;                                  // array extent (the f32 instantiation never runs that code)
     constexpr int STAGE = PREC == 0 ? (BM + BN) * KC : BM * KC + NPL * BN * 16;   // floats per stage: A rows, then B rows / B planes
-    constexpr int EPR = 128 * BN <= STAGE ? 128 : 64;   // rows of the epilogue staging tile (it reuses stage 0)
-    static_assert(EPR * BN <= STAGE, "epilogue tile fits one stage");
     static_assert(NPA >= 1 && NPA <= 8 && NPA * RP == BM, "A passes");
     static_assert(NPB >= 1 && NPB <= 4 && NPB * RP == BN, "B passes");
     static_assert(TM >= 1 && TN >= 1, "wave tile");
@@ -446,79 +444,74 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
       if (m0 + t < M) a.out[(size_t)(m0 + t) * a.Cout + n0] = sacc;
       return; }
 #endif
-    // epilogue: accumulators -> LDS tile [128][BN] (C/D layout: col = lane & 31 is the output channel,
-    // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) the pixel) -> BN fold / bias, residual, ReLU on float4 rows ->
-    // 16-byte coalesced stores (one wave writes 1 KiB contiguous).
+    // epilogue, wave-private: every wave takes ITS OWN (32 TM) x (32 TN) block of outputs through a private slab of the two stages (all
+    // fragment reads of the last chunk are behind the loop's closing barrier, no DMA is in flight) -- accumulators in (C/D layout: col =
+    // lane & 31 the output channel, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) the pixel), float4 rows out, BN fold / bias, residual, ReLU,
+    // 16-byte stores.  No workgroup barrier: LDS operations of one wave execute in order, so a wave whose MFMAs have drained stores while
+    // the others still compute (the shared [128][BN] tile of rounds 1-2 needed two to three barriers per tile; measured difference small:
+    // 249.4 -> 248.2 ms per pass).
     {
-        constexpr int NPASS = BM / EPR;
-        constexpr int V4 = BN / 4;
-        constexpr int RPI = NT / V4;             // rows per store iteration
-        float *Cs = stage0;
-        const int cv = (t % V4) * 4, r0 = t / V4;
-        const int co = n0 + cv;
+        constexpr int WROWS = TM * 32, WCOLS = TN * 32;      // the wave's block
+        constexpr int V4W = WCOLS / 4;                       // float4 per row
+        constexpr int RPW = 64 / V4W;                        // rows per store iteration of one wave
+        constexpr int PW = WROWS * WCOLS;
+        constexpr int WPS = (WM * WN) / 2;                   // waves per stage
+        static_assert(PW * WPS <= STAGE, "wave-private epilogue slabs fit the two stages");
+        float *Ws = (wave < WPS ? stage0 : stage1) + (wave % WPS) * PW;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+                for (int jn = 0; jn < TN; jn++) Ws[row * WCOLS + jn * 32 + (lane & 31)] = acc[i][jn][r];
+            }
+        const int quad = lane % V4W, rsub = lane / V4W;
+        const int co = n0 + wn * (BN / WN) + quad * 4;
         float4 sc = make_float4(0.f, 0.f, 0.f, 0.f);
         const float4 sh = *reinterpret_cast<const float4 *>(a.shift + co);
         if (a.scale) sc = *reinterpret_cast<const float4 *>(a.scale + co);
         const int rH = Ho >> a.rs, rW = Wo >> a.rs;
-        const int wrow0 = wm * (BM / WM);
-        // Addressing without vector arithmetic where the output is linear in m (everything but the sub-pixel scatter): uniform
-        // 64-bit base (tile, iteration) + a 32-bit per-lane offset that is fixed for the kernel (global_store ... saddr form).
-        // (raw_buffer_store_b128 with the tile in the descriptor and the iteration in soffset looked equivalent and was NOT: the
-        // network's outputs differed in the last bits from run to run, tests/test_gpu_unet.py; left aside, not understood.)
-        const bool full = m0 + BM <= M;
-        const unsigned vo = (unsigned)(r0 * a.Cout + cv) * 4u;
+        const int mw = m0 + wm * (BM / WM);                  // first output pixel of the wave's block
+        const bool full = mw + WROWS <= M;
+        const unsigned vo = (unsigned)(rsub * a.Cout + quad * 4) * 4u;
         const float relu_lo = a.relu_out ? 0.f : -__builtin_inff();
-#pragma unroll
-        for (int pass = 0; pass < NPASS; pass++) {
-            if (wrow0 / EPR == pass) {
-#pragma unroll
-                for (int i = 0; i < TM; i++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int row = wrow0 % EPR + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-#pragma unroll
-                        for (int jn = 0; jn < TN; jn++) Cs[row * BN + wn * (BN / WN) + jn * 32 + (lane & 31)] = acc[i][jn][r];
-                    }
-            }
-            __syncthreads();
-            const size_t tbase = (size_t)(m0 + pass * EPR) * a.Cout + n0;
-            char *const obase = reinterpret_cast<char *>(a.out + tbase);
-            const char *const rbase = reinterpret_cast<const char *>(a.resid + tbase);       // used for rs == 0 only
+        const size_t tbase = (size_t)mw * a.Cout + n0 + wn * (BN / WN);
+        char *const obase = reinterpret_cast<char *>(a.out + tbase);
+        const char *const rbase = reinterpret_cast<const char *>(a.resid + tbase);       // used for rs == 0 only
 #pragma unroll 4
-            for (int it = 0; it < EPR / RPI; it++) {
-                const int row = it * RPI + r0;
-                const int m = m0 + pass * EPR + row;
-                const bool ok = full || m < M;
-                const size_t so = (size_t)(it * RPI) * a.Cout * 4;
-                float4 v = *reinterpret_cast<const float4 *>(Cs + row * BN + cv);
-                if (a.scale) { v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w); }
-                else { v.x = v.x + sh.x; v.y = v.y + sh.y; v.z = v.z + sh.z; v.w = v.w + sh.w; }
-                if (a.resid) {
-                    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (a.rs) {
-                        if (ok) {
-                            const int n = fdiv(m, dHW);
-                            const int rr = m - n * (Ho * Wo);
-                            const int y = fdiv(rr, dW), x = rr - y * Wo;
-                            const size_t ridx = ((size_t)n * rH + (y >> a.rs)) * rW + (x >> a.rs);
-                            rv = *reinterpret_cast<const float4 *>(a.resid + ridx * a.Cout + co);
-                        }
-                    } else if (ok) rv = *reinterpret_cast<const float4 *>(rbase + so + vo);
-                    v.x = v.x + rv.x; v.y = v.y + rv.y; v.z = v.z + rv.z; v.w = v.w + rv.w;
-                }
-                v.x = fmaxf(v.x, relu_lo); v.y = fmaxf(v.y, relu_lo); v.z = fmaxf(v.z, relu_lo); v.w = fmaxf(v.w, relu_lo);
-                if (KS == 2) {      // scatter to the parity class's pixels of the (2 Ho, 2 Wo) output
+        for (int it = 0; it < WROWS / RPW; it++) {
+            const int row = it * RPW + rsub;
+            const int m = mw + row;
+            const bool ok = full || m < M;
+            const size_t so = (size_t)(it * RPW) * a.Cout * 4;
+            float4 v = *reinterpret_cast<const float4 *>(Ws + row * WCOLS + quad * 4);
+            if (a.scale) { v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w); }
+            else { v.x = v.x + sh.x; v.y = v.y + sh.y; v.z = v.z + sh.z; v.w = v.w + sh.w; }
+            if (a.resid) {
+                float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.rs) {
                     if (ok) {
                         const int n = fdiv(m, dHW);
                         const int rr = m - n * (Ho * Wo);
                         const int y = fdiv(rr, dW), x = rr - y * Wo;
-                        const size_t oidx = ((size_t)n * 2 * Ho + 2 * y + spy) * (2 * Wo) + 2 * x + spx;
-                        *reinterpret_cast<float4 *>(a.out + oidx * a.Cout + co) = v;
+                        const size_t ridx = ((size_t)n * rH + (y >> a.rs)) * rW + (x >> a.rs);
+                        rv = *reinterpret_cast<const float4 *>(a.resid + ridx * a.Cout + co);
                     }
-                }
-                else if (ok) *reinterpret_cast<float4 *>(obase + so + vo) = v;
+                } else if (ok) rv = *reinterpret_cast<const float4 *>(rbase + so + vo);
+                v.x = v.x + rv.x; v.y = v.y + rv.y; v.z = v.z + rv.z; v.w = v.w + rv.w;
             }
-            if (pass + 1 < NPASS) __syncthreads();
+            v.x = fmaxf(v.x, relu_lo); v.y = fmaxf(v.y, relu_lo); v.z = fmaxf(v.z, relu_lo); v.w = fmaxf(v.w, relu_lo);
+            if (KS == 2) {      // scatter to the parity class's pixels of the (2 Ho, 2 Wo) output
+                if (ok) {
+                    const int n = fdiv(m, dHW);
+                    const int rr = m - n * (Ho * Wo);
+                    const int y = fdiv(rr, dW), x = rr - y * Wo;
+                    const size_t oidx = ((size_t)n * 2 * Ho + 2 * y + spy) * (2 * Wo) + 2 * x + spx;
+                    *reinterpret_cast<float4 *>(a.out + oidx * a.Cout + co) = v;
+                }
+            }
+            else if (ok) *reinterpret_cast<float4 *>(obase + so + vo) = v;
         }
     }
 }
