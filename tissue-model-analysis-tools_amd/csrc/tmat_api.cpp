@@ -564,7 +564,9 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
         tmat_destroy((tmat_handle)c); return TMAT_E_HIP;
     }
     for (int i = 0; i < 2; i++)
-        if (!hip_ok(hipEventCreateWithFlags(&c->ev_down[i], hipEventDisableTiming), "hipEventCreate")) { tmat_destroy((tmat_handle)c); return TMAT_E_HIP; }
+        if (!hip_ok(hipEventCreateWithFlags(&c->ev_down[i], hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&c->ev_blend[i], hipEventDisableTiming), "hipEventCreate")) { tmat_destroy((tmat_handle)c); return TMAT_E_HIP; }
     const size_t pp = (size_t)patch * patch * c->max_patches * sizeof(float);
     c->scratch_bytes = 64 << 20;
     if (!hip_ok(hipMalloc((void **)&c->patch_in, pp), "hipMalloc(patch_in)") ||
@@ -615,7 +617,7 @@ void tmat_destroy(tmat_handle h)
     if (c->stream2) hipStreamSynchronize(c->stream2);
     for (int i = 0; i < 4; i++) if (c->buf[i]) hipFree(c->buf[i]);
     for (int i = 0; i < 4; i++) if (c->ubuf[i]) hipFree(c->ubuf[i]);
-    for (int i = 0; i < 2; i++) { if (c->dout[i]) hipFree(c->dout[i]); if (c->ev_down[i]) hipEventDestroy(c->ev_down[i]); }
+    for (int i = 0; i < 2; i++) { if (c->dout[i]) hipFree(c->dout[i]); if (c->ev_down[i]) hipEventDestroy(c->ev_down[i]); if (c->ev_up[i]) hipEventDestroy(c->ev_up[i]); if (c->ev_blend[i]) hipEventDestroy(c->ev_blend[i]); }
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->stream3) { hipStreamSynchronize(c->stream3); hipStreamDestroy(c->stream3); }
     if (c->patch_in) hipFree(c->patch_in);

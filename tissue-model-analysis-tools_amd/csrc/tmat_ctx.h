@@ -107,6 +107,8 @@ struct Ctx {
     hipStream_t stream2 = nullptr;                           // second stream: down path of pass p+1 overlaps up path of pass p
     hipStream_t stream3 = nullptr;                           // third stream: finish stage of pass p-1 (after the host thinning)
     hipEvent_t ev_down[2] = {nullptr, nullptr};
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_blend[2] = {nullptr, nullptr};      // the tail of a pass (blend, mask filter, EDT) on the second stream
+    bool blend_pending[2] = {false, false};
     float *patch_in = nullptr, *patch_out = nullptr;
     float input_sat = 65535.f;                               // Lanczos saturation: 65535, or 255 for 8-bit sources (tmat_set_input_depth)
     int patch_cap = 0;                                       // patches patch_in / patch_out hold (>= max_patches)
