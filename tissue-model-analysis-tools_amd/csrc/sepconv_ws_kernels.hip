@@ -34,6 +34,7 @@ namespace tmat {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // LDS map (floats): [A0 | X | A1 | B0 | B1 | H0 H1 H2 H3].  The pooling epilogue's exchange buffer (9216 floats) lies over
 // the A stage the tile's last step has just consumed plus the gap X: [A0 | X] or [X | A1].
@@ -75,7 +76,11 @@ __device__ long long ws_tl[12 * 2 * 14];         // absolute stamps of workgroup
 #define WS_DIAG_FLUSH()
 #endif
 
-template <bool RELU_IN, bool POOL>
+// PREC = 0: f32 MFMAs (the bit-exact path).  PREC = 1: the opt-in "bf16x3" mode of tmat_set_precision (unet_kernels.hip) for the
+// POINTWISE contraction only: the depthwise values stay f32 (producers unchanged, A operand f32 in LDS) and are split into bf16 hi / lo in
+// the consumers' registers; a.pwk then points to the host-split weights, two bf16 planes [plane][Cout][Cin]; three
+// v_mfma_f32_32x32x16_bf16 (lo hi, hi lo, hi hi) replace eight f32 MFMAs.  Same accumulator layout, same epilogues.
+template <bool RELU_IN, bool POOL, int PREC = 0>
 __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, int nNt, int G)
 {
     __shared__ __attribute__((aligned(16))) float smem[WS_TOTAL];
@@ -118,6 +123,7 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
         // channel group (lane & 7) ^ ((row >> 1) & 7) = (lane & 7) ^ ((4i + (lane >> 4)) & 7)
         const unsigned bvo0 = (unsigned)((32 * p + (lane >> 3)) * Cin * 4 + (((lane & 7) ^ (lane >> 4)) * 16));
         const unsigned bvo1 = (unsigned)((32 * p + 8 + (lane >> 3)) * Cin * 4 + (((lane & 7) ^ (4 + (lane >> 4))) * 16));
+        const unsigned bvo_p = (unsigned)((64 * (p & 1) + (lane >> 2)) * Cin * 2 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));      // PREC = 1
 
         // Halo addressing.  Piece i of the 13 LDS-DMA pieces carries halo pixels 8i .. 8i+7 (hp = 8i + (lane >> 3), row hp / 10,
         // column hp % 10 of the 10 x 10 halo), 16 bytes of channel quad lane & 7 per lane.  rel[i] is the lane's byte offset from
@@ -192,12 +198,24 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
             {
                 const int nt = pj % nNt;
                 float *Bs = smem + (stage ? WS_B1 : WS_B0);
-                const __amdgpu_buffer_rsrc_t rsB =
-                    __builtin_amdgcn_make_buffer_rsrc((void *)(a.pwk + (size_t)nt * 128 * Cin), 0, 0x7fffffff, 0x00020000);
+                if (PREC == 0) {
+                    const __amdgpu_buffer_rsrc_t rsB =
+                        __builtin_amdgcn_make_buffer_rsrc((void *)(a.pwk + (size_t)nt * 128 * Cin), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-                for (int i = 0; i < 4; i++)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t *)(Bs + (4 * p + i) * 256), 16,
-                                                             (i & 1) ? bvo1 : bvo0, pc * 128 + (i >> 1) * 16 * Cin * 4, 0, 0);
+                    for (int i = 0; i < 4; i++)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t *)(Bs + (4 * p + i) * 256), 16,
+                                                                 (i & 1) ? bvo1 : bvo0, pc * 128 + (i >> 1) * 16 * Cin * 4, 0, 0);
+                } else {
+                    // two bf16 planes of [128 rows][32 channels] = 64-byte rows; piece q = 4 p + i (1 KiB = 16 rows) of the 16: plane q >> 3,
+                    // rows 16 (q & 7) + (lane >> 2), 16-byte unit (lane & 3) ^ ((row >> 2) & 3) of the row's 64 bytes
+                    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+                        (void *)(reinterpret_cast<const char *>(a.pwk) + (size_t)nt * 128 * Cin * 2), 0, 0x7fffffff, 0x00020000);
+                    const int plane = (p >> 1) * a.Cout * Cin * 2;
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t *)(Bs + (4 * p + i) * 256), 16, bvo_p,
+                                                                 pc * 64 + plane + i * 16 * Cin * 2, 0, 0);
+                }
             }
             if (++pc == nchunks) { pc = 0; pj++; }
             WS_STAMP(0)
@@ -490,10 +508,20 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
             _Pragma("unroll") for (int jn = 0; jn < 4; jn++) acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(g) & 1].z, bv[(g) & 1][jn].z, acc[jn], 0, 0, 0); \
             _Pragma("unroll") for (int jn = 0; jn < 4; jn++) acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(g) & 1].w, bv[(g) & 1][jn].w, acc[jn], 0, 0, 0); \
         }
-    {
+    // PREC = 1: weight fragments of one k step (16 channels): plane pl, column block jn -> 8 bf16 of row jn 32 + r, unit (2 tk + h) ^ ((r >> 2) & 3)
+    bf16x8 wq[2][4];
+    const int boffp = r * 16, keyb = (r >> 2) & 3;
+#define WS_READ_BP(tk, Bp)                                                                                      \
+        _Pragma("unroll") for (int pl = 0; pl < 2; pl++)                                                        \
+            _Pragma("unroll") for (int jn = 0; jn < 4; jn++)                                                    \
+                wq[pl][jn] = *reinterpret_cast<const bf16x8 *>((Bp) + pl * 2048 + jn * 512 + boffp + ((((2 * (tk)) + h) ^ keyb) * 4));
+    if (PREC == 0) {
         const float *B0 = smem + WS_B0 + boffc;
         WS_READ_B(0, B0)
         WS_READ_B(1, B0)
+    } else {
+        const float *B0 = smem + WS_B0;
+        WS_READ_BP(0, B0)
     }
     int cj = j0, cc = 0;
     for (int s = 0; s < total; s++) {
@@ -507,6 +535,40 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
         const float *As = smem + (stage ? WS_A1 : WS_A0) + aoffc;
         const float *Bs = smem + (stage ? WS_B1 : WS_B0) + boffc;
         WS_TL(0)
+        if (PREC == 1) {
+            // k step tk covers channels 16 tk .. 16 tk + 15; a lane's 8 values are channels 16 tk + 8 h + j: 16-byte units 4 tk + 2 h and
+            // 4 tk + 2 h + 1 of its f32 row
+            float4 af[2][2];
+#pragma unroll
+            for (int tk = 0; tk < 2; tk++) {
+                af[tk][0] = *reinterpret_cast<const float4 *>(As + (((4 * tk + 2 * h) ^ key) * 4));
+                af[tk][1] = *reinterpret_cast<const float4 *>(As + (((4 * tk + 2 * h + 1) ^ key) * 4));
+            }
+            WS_PIN()
+#pragma unroll
+            for (int tk = 0; tk < 2; tk++) {
+                if (tk == 1) {              // the second k step's weights: behind the first one's MFMAs, into the same registers
+                    const float *Bq = smem + (stage ? WS_B1 : WS_B0);
+                    WS_READ_BP(1, Bq)
+                    WS_PIN()
+                }
+                const float xs[8] = {af[tk][0].x, af[tk][0].y, af[tk][0].z, af[tk][0].w, af[tk][1].x, af[tk][1].y, af[tk][1].z, af[tk][1].w};
+                bf16x8 ahi, alo;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const __bf16 q = (__bf16)xs[j];
+                    ahi[j] = q;
+                    alo[j] = (__bf16)(xs[j] - (float)q);
+                }
+#pragma unroll
+                for (int jn = 0; jn < 4; jn++) {        // smallest products first: lo hi, hi lo, hi hi
+                    acc[jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, wq[0][jn], acc[jn], 0, 0, 0);
+                    acc[jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, wq[1][jn], acc[jn], 0, 0, 0);
+                    acc[jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, wq[0][jn], acc[jn], 0, 0, 0);
+                }
+                WS_PIN()
+            }
+        } else {
         WS_READ_A(0)
         WS_READ_A(1)
         WS_PIN()
@@ -532,6 +594,7 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
         WS_TL(4)
         WS_MM(3)
         WS_PIN()
+        }
         WS_TL(5)
         WS_STAMP(1)
         WS_BAR()                                             // vector phase: the producers compute the next step's A operand
@@ -551,9 +614,14 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
         }
         WS_PIN()
         if (s + 1 < total) {
-            const float *Bn = smem + (stage ? WS_B0 : WS_B1) + boffc;
-            WS_READ_B(0, Bn)
-            WS_READ_B(1, Bn)
+            if (PREC == 0) {
+                const float *Bn = smem + (stage ? WS_B0 : WS_B1) + boffc;
+                WS_READ_B(0, Bn)
+                WS_READ_B(1, Bn)
+            } else {
+                const float *Bn = smem + (stage ? WS_B0 : WS_B1);
+                WS_READ_BP(0, Bn)
+            }
         }
         WS_PIN()
         WS_STAMP(3)
@@ -564,6 +632,7 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
     }
 #undef WS_READ_A
 #undef WS_READ_B
+#undef WS_READ_BP
 #undef WS_MM
 #ifdef WS_DIAG
     dsum[7] = total;
@@ -590,11 +659,14 @@ static int ws_cus()
 }
 
 template <bool POOL>
-static void launch_ws_any(const WsArgs &a, int relu_in, hipStream_t s)
+static void launch_ws_any(const WsArgs &a, int relu_in, int prec, hipStream_t s)
 {
     const int nMt = a.N * (a.H / 16) * (a.W / 16), nNt = a.Cout / 128;
     const int G = (ws_cus() / 8) * 8;                       // one persistent 12-wave workgroup per CU (152 KiB of LDS)
-    if (relu_in) hipLaunchKernelGGL((sepconv_ws_kernel<true, POOL>), dim3(G), dim3(768), 0, s, a, nMt, nNt, G);
+    if (prec == 1) {
+        if (relu_in) hipLaunchKernelGGL((sepconv_ws_kernel<true, POOL, 1>), dim3(G), dim3(768), 0, s, a, nMt, nNt, G);
+        else hipLaunchKernelGGL((sepconv_ws_kernel<false, POOL, 1>), dim3(G), dim3(768), 0, s, a, nMt, nNt, G);
+    } else if (relu_in) hipLaunchKernelGGL((sepconv_ws_kernel<true, POOL>), dim3(G), dim3(768), 0, s, a, nMt, nNt, G);
     else hipLaunchKernelGGL((sepconv_ws_kernel<false, POOL>), dim3(G), dim3(768), 0, s, a, nMt, nNt, G);
 #ifdef WS_DIAG
     {
@@ -626,14 +698,14 @@ static void launch_ws_any(const WsArgs &a, int relu_in, hipStream_t s)
 }
 
 bool launch_sepconv_ws(const float *in, int N, int H, int W, int Cin, int relu_in, const float *dw9, const float *pwk, int Cout,
-                       const float *scale, const float *shift, int relu_out, float *out, hipStream_t s)
+                       const float *scale, const float *shift, int relu_out, float *out, hipStream_t s, int prec)
 {
     if (!sepconv_ws_supported(H, W, Cin, Cout) || N <= 0 || (long long)N * (H / 16) * (W / 16) * (Cout / 128) > 0x3fffffffLL) {
         set_error("launch_sepconv_ws: unsupported shape");
         return false;
     }
     WsArgs a{in, N, H, W, Cin, Cout, dw9, pwk, scale, shift, relu_out, out, nullptr, nullptr, nullptr, nullptr};
-    launch_ws_any<false>(a, relu_in, s);
+    launch_ws_any<false>(a, relu_in, prec, s);
     return true;
 }
 
@@ -642,7 +714,7 @@ void launch_pool_fix_add(float *out, const float *sh, const float *sv, const flo
                          hipStream_t s);
 
 bool launch_sepconv_pool_ws(const float *in, int N, int H, int W, int Cin, int relu_in, const float *dw9, const float *pwk, int Cout,
-                            const float *scale, const float *shift, int relu_out, float *scratch, const float *resid, float *out, hipStream_t s)
+                            const float *scale, const float *shift, int relu_out, float *scratch, const float *resid, float *out, hipStream_t s, int prec)
 {
     if (!sepconv_ws_supported(H, W, Cin, Cout) || N <= 0 || (long long)N * (H / 16) * (W / 16) * (Cout / 128) > 0x3fffffffLL ||
         ((Cout / 4) & (Cout / 4 - 1))) {
@@ -652,7 +724,7 @@ bool launch_sepconv_pool_ws(const float *in, int N, int H, int W, int Cin, int r
     const size_t tiles = (size_t)N * (H / 16) * (W / 16);
     float *sh = scratch, *sv = sh + tiles * 8 * Cout, *co = sv + tiles * 8 * Cout;
     WsArgs a{in, N, H, W, Cin, Cout, dw9, pwk, scale, shift, relu_out, out, resid, sh, sv, co};
-    launch_ws_any<true>(a, relu_in, s);
+    launch_ws_any<true>(a, relu_in, prec, s);
     launch_pool_fix_add(out, sh, sv, co, resid, N, H, W, Cout, 8, s);
     return true;
 }

@@ -325,17 +325,25 @@ int unet_down_dev(Ctx *c, const float *X, int n, float *dout, hipStream_t s)
         // prev = b0 (n, H, H, cin)
         if (c->fused_sep && c->sep_ws && sepconv_ws_supported(H, H, d.cin, d.cout) && sepconv_ws_supported(H, H, d.cout, d.cout) &&
             ((d.cout / 4) & (d.cout / 4 - 1)) == 0) {
-            // wave-specialised fused kernels (sepconv_ws_kernels.hip): depthwise producers + MFMA consumers in one workgroup
-            if (!launch_sepconv_ws(b0, n, H, H, d.cin, bi > 0, d.dw[0], d.pw[0], d.cout, d.scale[0], d.shift[0], 1, b2, s)) return TMAT_E_ARG;
+            // wave-specialised fused kernels (sepconv_ws_kernels.hip): depthwise producers + MFMA consumers in one workgroup.
+            // bf16x3 mode: the pointwise contraction on the split weights (bf16x6 keeps these layers in f32: three planes do not fit the LDS budget)
+            const float *pw0 = d.pw[0], *pw1 = d.pw[1];
+            int sprec = 0;
+            if (c->precision == TMAT_PRECISION_BF16X3 && c->sep_bf16) {
+                auto &mp = c->wsplit[c->precision];
+                auto i0 = mp.find(d.pw[0]), i1 = mp.find(d.pw[1]);
+                if (i0 != mp.end() && i1 != mp.end()) { pw0 = i0->second; pw1 = i1->second; sprec = 1; }
+            }
+            if (!launch_sepconv_ws(b0, n, H, H, d.cin, bi > 0, d.dw[0], pw0, d.cout, d.scale[0], d.shift[0], 1, b2, s, sprec)) return TMAT_E_ARG;
             ConvArgs r{};
             r.in = b0; r.N = n; r.h = H; r.w = H; r.Cin = d.cin; r.ksize = 1; r.stride = 2; r.W = d.res_w; r.Cout = d.cout;
             r.scale = nullptr; r.shift = d.res_b; r.out = b1;
             if (!conv(c, r, s)) return TMAT_E_ARG;
             float *nxt = bi + 1 == c->down.size() ? dout : b0;
             if (c->fused_pool) {
-                if (!launch_sepconv_pool_ws(b2, n, H, H, d.cout, 0, d.dw[1], d.pw[1], d.cout, d.scale[1], d.shift[1], 0, b3, b1, nxt, s)) return TMAT_E_ARG;
+                if (!launch_sepconv_pool_ws(b2, n, H, H, d.cout, 0, d.dw[1], pw1, d.cout, d.scale[1], d.shift[1], 0, b3, b1, nxt, s, sprec)) return TMAT_E_ARG;
             } else {
-                if (!launch_sepconv_ws(b2, n, H, H, d.cout, 0, d.dw[1], d.pw[1], d.cout, d.scale[1], d.shift[1], 0, b3, s)) return TMAT_E_ARG;
+                if (!launch_sepconv_ws(b2, n, H, H, d.cout, 0, d.dw[1], pw1, d.cout, d.scale[1], d.shift[1], 0, b3, s, sprec)) return TMAT_E_ARG;
                 launch_maxpool_add(b3, n, H, H, d.cout, b1, nxt, s);
             }
             H /= 2;
@@ -527,6 +535,7 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
     if (const char *e = getenv("TMAT_FUSED_SEP")) c->fused_sep = atoi(e) != 0;
     if (const char *e = getenv("TMAT_FUSED_POOL")) c->fused_pool = atoi(e) != 0;
     if (const char *e = getenv("TMAT_SEP_WS")) c->sep_ws = atoi(e) != 0;
+    if (const char *e = getenv("TMAT_SEP_BF16")) c->sep_bf16 = atoi(e) != 0;
     const char *prec_env = getenv("TMAT_PRECISION");
     if (prec_env && strcmp(prec_env, "f32") && strcmp(prec_env, "bf16x3") && strcmp(prec_env, "bf16x6")) {
         set_error("tmat_create: TMAT_PRECISION must be f32, bf16x3 or bf16x6");

@@ -149,6 +149,7 @@ struct Ctx {
     std::map<const float *, ConvWHost> conv_w_host;          // device pointer of every MFMA convolution weight tensor -> its host copy
     std::map<int, std::map<const float *, float *>> wsplit;  // precision mode -> (... -> its split-precision copy on the device, made on first use)
     bool sep_ws = true;                                      // wave-specialised form of the fused separable kernel (TMAT_SEP_WS=0: sepconv_mfma_kernel)
+    bool sep_bf16 = true;                                    // bf16x3 mode also runs the separable layers' pointwise part on the bf16 cores (TMAT_SEP_BF16=0: f32)
     bool fused_sep = true;                                   // fused depthwise->pointwise kernel where the level allows (TMAT_FUSED_SEP=0: off)
     // profiling of the dominant kernel family
     bool prof_on = false;

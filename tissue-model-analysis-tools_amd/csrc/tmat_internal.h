@@ -41,9 +41,9 @@ bool launch_sepconv_pool(const float *in, int N, int H, int W, int Cin, int relu
 // wave-specialised form (sepconv_ws_kernels.hip): depthwise taps dw9 [9][Cin], pointwise pwk [Cout][Cin]; same results, same strips
 bool sepconv_ws_supported(int H, int W, int Cin, int Cout);
 bool launch_sepconv_ws(const float *in, int N, int H, int W, int Cin, int relu_in, const float *dw9, const float *pwk, int Cout,
-                       const float *scale, const float *shift, int relu_out, float *out, hipStream_t s);
+                       const float *scale, const float *shift, int relu_out, float *out, hipStream_t s, int prec = 0);
 bool launch_sepconv_pool_ws(const float *in, int N, int H, int W, int Cin, int relu_in, const float *dw9, const float *pwk, int Cout,
-                            const float *scale, const float *shift, int relu_out, float *scratch, const float *resid, float *out, hipStream_t s);
+                            const float *scale, const float *shift, int relu_out, float *scratch, const float *resid, float *out, hipStream_t s, int prec = 0);
 void launch_dwconv(const float *in, int N, int H, int W, int C, int relu_in, const float *Wd, float *out, hipStream_t s);
 void launch_stem(const float *x, int N, int H, int W, const float *Ws, int Cout, const float *scale,
                  const float *shift, float *out, hipStream_t s);
