@@ -579,10 +579,12 @@ bool launch_conv(const ConvArgs &a, hipStream_t s)
     const int M = (int)Mll;
     if (a.Cout % 128 == 0)
         launch_conv_cfg<TMAT_BM, 128, TMAT_WM, TMAT_WN>(a, M, Ho, Wo, s);
-    else if (a.ksize == 2 && a.prec == 0)
+    else if (a.ksize == 2)
         // the sub-pixel layer with 64 output channels (16 chunks per tile, four parity classes): 256 x 64 tiles of eight 32 x 64 wave blocks
         // -- 32 MFMAs per wave and chunk instead of 16 -- measure 20.6 against 21.5 ms; the 3 x 3 layer prefers 128 x 64 (22.7 against 23.2)
         launch_conv_ks<256, 64, 8, 1, 2>(a, M, Ho, Wo, s);
+    else if (a.ksize == 3 && a.prec != 0)          // split precision: a chunk is short, the A-tile traffic per MFMA decides (12.5 -> 11.4 ms in bf16x3)
+        launch_conv_ks<256, 64, 8, 1, 3>(a, M, Ho, Wo, s);
     else
         launch_conv_cfg<TMAT_64_BM, 64, TMAT_64_WM, TMAT_64_WN>(a, M, Ho, Wo, s);
     return true;
