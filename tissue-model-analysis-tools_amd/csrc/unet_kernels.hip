@@ -72,6 +72,9 @@ __device__ __forceinline__ int fdiv(int n, FastDiv f) { return (int)(__umulhi((u
 //   matrix pipe run side by side, unlike the f32 MFMA).  The WEIGHTS are split once on the host (tmat_api.cpp:split_bf16)
 //   into NPL = 2 / 3 bf16 PLANES [plane][tap][Cout][Cin]; a stage holds the A rows as in the f32 path and NPL weight planes
 //   of [BN rows][32 bf16] (64-byte rows, 16-byte unit u of row r in slot u ^ ((r >> 2) & 3): conflict-free ds_read_b128).
+#ifdef TMAT_DIAG
+__device__ long long conv_diag[2048 * 8 * 8];      // [workgroup < 2048][wave][work, dma wait, barrier, fill, chunks, 1, epilogue]
+#endif
 template <int BM, int BN, int WM, int WN, int KS, bool RELU, int PREC = 0>
 #ifndef TMAT_CONV_WPS
 #define TMAT_CONV_WPS 4     // waves per SIMD the 8-wave conv kernel is compiled for (VGPR budget 512 / this)
@@ -281,7 +284,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
 #else
 // every wave retires its own DMA (explicitly: the ordering of LDS-DMA data for the readers is this wait followed by the
 // barrier, and must not depend on what hipcc chooses to put in front of a barrier), then the workgroup barrier
+#ifdef TMAT_DIAG      // diagnostic build: cycles a wave spends in the chunk's DMA wait, in the barrier, and in the rest of a step
+#define TMAT_LOOP_SYNC() { const long long d0_ = (long long)__builtin_readcyclecounter(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      \
+                           const long long d1_ = (long long)__builtin_readcyclecounter(); __syncthreads();                                       \
+                           const long long d2_ = (long long)__builtin_readcyclecounter(); dg_work += d0_ - dg_last; dg_vm += d1_ - d0_; dg_bar += d2_ - d1_; dg_last = d2_; }
+#else
 #define TMAT_LOOP_SYNC() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+#endif
 #endif
 #define TMAT_READ_FRAGS(stage_) TMAT_READ_FRAGS_RANGE(stage_, 0, 4)
 #define TMAT_READ_FRAGS_RANGE(stage_, G0, G1)                                          \
@@ -403,9 +412,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
         TMAT_LOOP_SYNC()                                                               \
     }
 
+#ifdef TMAT_DIAG
+    long long dg_work = 0, dg_vm = 0, dg_bar = 0;
+    const long long dg_t0 = (long long)__builtin_readcyclecounter();
+#endif
     TMAT_ISSUE_CHUNK(stage0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef TMAT_DIAG
+    long long dg_last = (long long)__builtin_readcyclecounter();
+    const long long dg_fill = dg_last - dg_t0;
+#endif
 
     // even chunks live in stage0, odd ones in stage1 (nchunks is even: host check)
     if (PREC == 0) {
@@ -438,6 +455,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
 #undef TMAT_DMA_B
 #undef TMAT_ISSUE_CHUNK
 
+#ifdef TMAT_DIAG
+    long long *dg_slot = conv_diag + ((size_t)(blockIdx.x < 2048 ? blockIdx.x : 0) * 8 + wave) * 8;
+    const bool dg_on = lane == 0 && KS == 3 && BN == 128 && !RELU && PREC == 0 && blockIdx.x < 2048;
+    if (dg_on) { dg_slot[0] = dg_work; dg_slot[1] = dg_vm; dg_slot[2] = dg_bar; dg_slot[3] = dg_fill; dg_slot[4] = nchunks; dg_slot[5] = 1; }
+    const long long dg_e0 = (long long)__builtin_readcyclecounter();
+#endif
 #ifdef TMAT_ABL_NOEPI      // timing ablation only (results are wrong): one store per lane instead of the epilogue
     { float sacc = 0.f;
       for (int i = 0; i < TM; i++) for (int jn = 0; jn < TN; jn++) for (int r = 0; r < 16; r++) sacc += acc[i][jn][r];
@@ -514,6 +537,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
             else if (ok) *reinterpret_cast<float4 *>(obase + so + vo) = v;
         }
     }
+#ifdef TMAT_DIAG
+    if (dg_on) dg_slot[6] = (long long)__builtin_readcyclecounter() - dg_e0;
+#endif
 }
 
 template <int BM, int BN, int WM, int WN, int KS>
@@ -542,6 +568,19 @@ static void launch_conv_ks(const ConvArgs &a, int M, int Ho, int Wo, hipStream_t
         hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, true>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt, dHW, dW, nstat);
     else
         hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WM, WN, KS, false>), grid, dim3(64 * WM * WN), 0, s, a, M, Ho, Wo, nMt, nNt, dHW, dW, nstat);
+#ifdef TMAT_DIAG
+    if (KS == 3 && BN == 128 && !a.relu_in) {
+        static long long zz[2048 * 8 * 8];
+        long long z[8] = {0};
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(zz, HIP_SYMBOL(conv_diag), sizeof(zz));
+        const int nb = grid.x < 2048 ? (int)grid.x : 2048;
+        for (int b = 0; b < nb; b++) for (int w8 = 0; w8 < 8; w8++) for (int k = 0; k < 7; k++) z[k] += zz[((size_t)b * 8 + w8) * 8 + k];
+        const double w = (double)z[5], ch = (double)z[4];
+        fprintf(stderr, "[convdiag] Cin %d h %d: per chunk and wave: work %.0f  dma wait %.0f  barrier %.0f cycles | per tile: fill %.0f  epilogue %.0f | chunks per tile %.0f\n",
+                a.Cin, a.h, z[0] / ch, z[1] / ch, z[2] / ch, z[3] / w, z[6] / w, ch / w);
+    }
+#endif
 }
 
 template <int BM, int BN, int WM, int WN>
