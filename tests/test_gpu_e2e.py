@@ -138,6 +138,37 @@ def test_gather_rows_over_rccl_single_rank(tmp_path):
     assert r.returncode == 0 and "gathered 5 rows over RCCL" in r.stdout, r.stdout + r.stderr
 
 
+STREAM_CHILD = r"""
+import json, sys
+sys.path[:0] = [r"{repo}", r"{repo}/tissue-model-analysis-tools_amd"]
+import numpy as np
+from tmat_amd import _lib, branches, synth
+h = _lib.Handle(synth.pack_weights(synth.synth_weights(0)), 0, 144)          # 72 patches per 512 x 512 image: two images per pass, five passes
+imgs = np.stack([synth.synth_image(100 + i, 512, n_vessels=12, scale=1.0) for i in range(9)])
+cfg = dict(graph_thresh_1=5, graph_thresh_2=10, graph_smoothing_window=12, min_branch_length=12, remove_isolated_branches=False)
+print(json.dumps([[int(r[0]), int(r[1]), repr(float(r[2])), repr(float(r[3]))] for r in branches.analyze_batch(h, imgs, cfg, 500.0)]))
+h.close()
+"""
+
+
+def test_stream_layouts_give_identical_rows(tmp_path):
+    """the pipeline's stream layouts are scheduling only: the tail of a pass on the second stream (default), everything on the main
+    stream (TMAT_TAIL_STREAM=0) and the two-stream network (TMAT_STREAMS=2) return the same rows over five passes of 9 images"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    script = tmp_path / "streams_child.py"
+    script.write_text(STREAM_CHILD.replace("{repo}", str(Path(__file__).resolve().parents[1])))
+    outs = []
+    for extra in ({}, {"TMAT_TAIL_STREAM": "0"}, {"TMAT_STREAMS": "2"}):
+        r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=dict(os.environ, **extra))
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1] == outs[2] and len(outs[0]) == 9 and sum(r[1] for r in outs[0]) > 0
+
+
 def test_rows_within_north_star_tolerance_of_the_as_written_network(handle, weights, images):
     """The north-star bar against the reference CPU path: integer branch counts equal, branch lengths within 1e-4
     relative.  The closest thing to that path available here is the oracle with the as-written network (PyTorch-CPU
