@@ -15,7 +15,7 @@ The reference's arithmetic here is scikit-image's (setup.py pins 0.22.0; only 0.
   ConvexHull, Delaunay.find_simplex -> scipy.spatial (qhull); the hull mask is restated as an exact integer
                     point-in-convex-polygon test and checked against Delaunay in tests/test_oracle_wellmask.py
 PINNED by tests/golden/wellmask.npz (tools/make_goldens.py wellmask: the reference module imported under scikit-image
-0.18.3 with the three bridges described there): thresholded mask, final mask and superellipse parameters, 10 cases.
+0.18.3 with the three bridges described there): thresholded mask, final mask and superellipse parameters, 14 cases (7 inputs x 2 seeds).
 The random superellipse search is unseeded in the reference (np.random.rand, :35); here the seed is explicit and the
 draw is RandomState(seed).rand(25000, 6) -- the same stream as np.random.seed(seed) followed by np.random.rand.
 """
