@@ -102,7 +102,8 @@ def cpu_baseline(img, weights, handle, log, n_sample_patches=40, repeats=3):
     total = t_pre + t_unet + t_blend + t_post
     log(f"  cpu baseline: pre {t_pre:.2f}s unet(scaled) {t_unet:.2f}s blend {t_blend:.2f}s post+graph {t_post:.2f}s")
     return {"value": round(1.0 / total, 5), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"one 1024x1024 image, every stage the median of {repeats} runs: all non-UNet stages in full; UNet on "
+            "kind_detail": "port (oracle/), 1-image sample",
+            "sample": f"1-image sample: one 1024x1024 image, every stage the median of {repeats} runs: all non-UNet stages in full; UNet on "
                       f"{n_sample_patches} of its 200 patches (time scaled by 200/{n_sample_patches}) with the faster of the oracle's two CPU implementations",
             "cpu_model": _cpu_model(), "os_cpu_count": os.cpu_count(), "torch_threads": int(torch.get_num_threads()),
             "seconds_per_image": round(total, 2), "unet_seconds_per_image": round(t_unet, 2),
@@ -207,6 +208,7 @@ def main():
 
         def step(n=n_img):
             return [(rank * n_img + i, int(host[i].sum() % 97), float(host[i].mean()), float(host[i].std())) for i in range(n)]
+        step_host = step
 
         def handle_sync():
             pass
@@ -223,6 +225,10 @@ def main():
         def step(n=n_img):
             return branches.analyze_batch(handle, (n, SIZE, SIZE), CFG, IMAGE_WIDTH_MICRONS, first_index=rank * n_img,
                                           dev_ptr=dptr.value)
+
+        def step_host(n=n_img):
+            # SURVEY 8d's metric as written: the uint16 arrays are in HOST memory when the clock starts (tmat_analyze_batch: H2D inside)
+            return branches.analyze_batch(handle, host[:n], CFG, IMAGE_WIDTH_MICRONS, first_index=rank * n_img)
 
         def handle_sync():
             _lib.check(L.tmat_sync(handle.raw), "sync")
@@ -249,6 +255,17 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     log(f"timed region {elapsed:.2f} s")
+    # second figure, outside the contract's timed region: the same step through the host-pointer entry (PCIe inclusive), a few steps
+    n_host_steps = max(1, min(3, args.steps))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(n_host_steps):
+        host_rows = step_host()
+    barrier()
+    elapsed_host = time.perf_counter() - t0
+    if [r[1:] for r in host_rows] != [r[1:] for r in rows]:
+        raise SystemExit("bench: the host-pointer entry and the device-pointer entry produced different rows")
+    log(f"host-input steps: {n_host_steps} in {elapsed_host:.2f} s")
     # HIP-event timing of the dominant kernel in a SEPARATE pass after the timed region (same kernels, same 1600-patch
     # launches: two passes of 8 images), on the stream the kernels are launched on.  Its rows double as a determinism /
     # race screen: the same images in another position of another run must give identical rows; tiled copies likewise.
@@ -267,9 +284,9 @@ def main():
             raise SystemExit(f"bench: image {i} and its copy {i % nd} produced different rows: {r} vs {rows[i % nd]}")
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if (stub or rehearse) else "cuda")
+        t = torch.tensor([elapsed, elapsed_host], dtype=torch.float64, device="cpu" if (stub or rehearse) else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, elapsed_host = float(t[0].item()), float(t[1].item())
         # the one collective of the path: a single fixed-size all-gather of the 32-byte result rows over RCCL/xGMI
         from tmat_amd import distributed
         n_rows = len(distributed.gather_rows(rows, n_total=n_img * world))
@@ -301,6 +318,10 @@ def main():
             "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "value_host_inputs": round(n_img * world * n_host_steps / elapsed_host, 4),
+            "value_host_inputs_note": f"SURVEY 8d's metric as written -- uint16 arrays in HOST memory when the clock starts (tmat_analyze_batch, "
+                                      f"2 MB/image of H2D inside the timed region), {n_host_steps} step(s) after the contract's timed region; "
+                                      "`value` is the contract's figure (inputs resident in HBM)",
             "config": {"workload": f"{n_img} synthetic 1024x1024 uint16 Z-projections per GPU ({len(distinct)} distinct), inputs pre-resident "
                                    "in HBM (host-pointer entry adds 2 MB/image of H2D), tiled UNet seg (200 patches/image, random-init "
                                    "structured weights) + DMT branch extraction, default_branching_computation.json",

@@ -22,6 +22,26 @@ def test_every_declared_symbol_is_exported():
     assert L.tmat_version() >= 0x100
 
 
+@pytest.mark.parametrize("src, flag", [("unet_kernels.hip", "TMAT_ABL_A9"), ("unet_kernels.hip", "TMAT_VAR_ORDER=2"),
+                                       ("sepconv_ws_kernels.hip", "WS_DIAG"), ("sepconv_kernels.hip", "SEP_ABL_NOMFMA")])
+def test_product_builds_refuse_ablation_and_variant_flags(src, flag):
+    """a wrong-result ablation (or a variant / diagnostic switch) cannot reach a product build: csrc/dev_guard.h stops the compile
+    unless -DTMAT_DEV_BUILD is given, which only tools/build_variant.sh passes (its output goes to build_variants/)"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    csrc = REPO / "tissue-model-analysis-tools_amd" / "csrc"
+    base = [hipcc, "-x", "hip", "-E", "--offload-arch=gfx950", "--cuda-device-only", "-std=c++17", str(csrc / src), "-o", "/dev/null"]
+    bad = subprocess.run(base + [f"-D{flag}"], capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "TMAT_DEV_BUILD" in bad.stderr, bad.stderr[-400:]
+    ok = subprocess.run(base + [f"-D{flag}", "-DTMAT_DEV_BUILD"], capture_output=True, text=True, timeout=300)
+    assert ok.returncode == 0, ok.stderr[-400:]
+    # and the product build script never defines the dev switch
+    assert "TMAT_DEV_BUILD" not in (REPO / "tools" / "build.py").read_text()
+    users = [p.name for p in (REPO / "tools").glob("*") if p.is_file() and "TMAT_DEV_BUILD" in p.read_text(errors="ignore")]
+    assert users == ["build_variant.sh"], users
+
+
 def test_create_fails_loudly_without_gpu_or_with_bad_blob():
     import ctypes as C
     L = _lib.lib()

@@ -142,8 +142,14 @@ def load_fn(i):
         print("cannot read", i, flush=True)
         raise branches.InputError(i)
     return np.full((8, 8), int(i[3:]), np.uint16)
+def analyze_fn(b, w, thresh, input_bits):
+    if "{mode}" == "analyze" and int(b.max()) >= 4:         # any exception out of the analyser (a HIP error, a shape surprise) on the last rank
+        raise RuntimeError("analyser failed on the batch that holds image %d" % int(b.max()))
+    return [(k, 1, 2.0, 3.0) for k in range(len(b))]
+if "{mode}" == "analyze":
+    load_fn = lambda i: np.full((8, 8), int(i[3:]), np.uint16)
 try:
-    branches.run_sharded(ids, load_fn, lambda i, im: 100.0, lambda b, w, thresh, input_bits: [(k, 1, 2.0, 3.0) for k in range(len(b))],
+    branches.run_sharded(ids, load_fn, lambda i, im: 100.0, analyze_fn,
                          dict(graph_thresh_1=[5, 7]), rank, ws, log=lambda m: None)
 except distributed.RankFailed:
     distributed.finish_process_group()
@@ -153,12 +159,14 @@ print("rank", rank, "unexpectedly succeeded")
 """
 
 
+@pytest.mark.parametrize("mode", ["load", "analyze"])
 @pytest.mark.parametrize("nproc", [1, 2])
-def test_a_rank_that_cannot_load_an_image_fails_the_whole_run_without_a_hang(tmp_path, nproc):
+def test_a_rank_that_cannot_load_an_image_fails_the_whole_run_without_a_hang(tmp_path, nproc, mode):
     """ADVICE (round 2): a rank that sys.exit()s inside its shard loop leaves the others blocked in the all-gather; the failure
-    now travels through the collective as a marker row and every rank exits with code 1"""
+    now travels through the collective as a marker row and every rank exits with code 1.  Round 3's ADVICE: the same for ANY
+    exception of the per-rank work ("analyze": the analyser raises on the last rank's batch), not only for an unreadable image."""
     script = tmp_path / "failing.py"
-    script.write_text(FAILING.format(repo=str(REPO)))
+    script.write_text(FAILING.format(repo=str(REPO), mode=mode))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):

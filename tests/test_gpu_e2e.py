@@ -202,6 +202,12 @@ def test_images_that_need_more_patches_than_the_workspace(weights, images, oracl
                                                  _lib.ptr(pred)), "segment")
         for i in range(len(images)):
             assert np.array_equal(pred[i].view(np.uint64), oracle_runs[i][1]["pred"].view(np.uint64))
+        # five oversize passes in a row: every pass's whole network runs in the front half and writes the single patch_out that the
+        # previous pass's blend reads on the second stream -- the front half waits for that blend (pipeline.cpp:enqueue_front)
+        five = np.ascontiguousarray(images[[0, 1, 1, 0, 1]])
+        rows5 = branches.analyze_batch(h, five, CFG, 500.0)
+        for r, i in zip(rows5, [0, 1, 1, 0, 1]):
+            assert (r[1], r[2], r[3]) == tuple(oracle_runs[i][0]), i
         # a second geometry on the same handle afterwards (buffers regrow / are reused)
         small = synth.synth_image(4, 256, n_vessels=10, scale=1.0)
         big = _lib.Handle(synth.pack_weights(weights), 0, 128)

@@ -46,49 +46,54 @@ static int ensure_pass_buffers(Ctx *c, int K, int H, int W, int h, int w, int fh
     TMAT_HIP(hipMemcpy(b.xc, xc.data(), xc.size() * 4, hipMemcpyHostToDevice));
     TMAT_HIP(hipMemcpy(b.yi, yi.data(), yi.size() * 4, hipMemcpyHostToDevice));
     TMAT_HIP(hipMemcpy(b.yc, yc.data(), yc.size() * 4, hipMemcpyHostToDevice));
-    TMAT_HIP(hipMalloc((void **)&b.tmp, (size_t)K * H * w * sizeof(float)));
-    TMAT_HIP(hipMalloc((void **)&b.small, (size_t)K * h * w * sizeof(uint16_t)));
-    TMAT_HIP(hipMalloc((void **)&b.x, (size_t)K * h * w * sizeof(float)));
-    TMAT_HIP(hipMalloc((void **)&b.mn, (size_t)K * sizeof(int))); TMAT_HIP(hipMalloc((void **)&b.mx, (size_t)K * sizeof(int)));
-    TMAT_HIP(hipMalloc(&b.morph_ws, morph_workspace_bytes(K, h, w)));
-    TMAT_HIP(hipMalloc(&b.finish_ws, finish_workspace_bytes(K, h, w, fh, fw)));
+    // every scratch buffer is recorded with its size: tmat_debug_poison (test-only) fills them between calls
+#define DALLOC(ptr_, bytes_) { const size_t nb_ = (bytes_); TMAT_HIP(hipMalloc((void **)&(ptr_), nb_)); b.ws.push_back(WsEnt{(void *)(ptr_), nb_, false}); }
+#define HALLOC(ptr_, bytes_) { const size_t nb_ = (bytes_); TMAT_HIP(hipHostMalloc((void **)&(ptr_), nb_, hipHostMallocDefault)); b.ws.push_back(WsEnt{(void *)(ptr_), nb_, true}); }
+    DALLOC(b.tmp, (size_t)K * H * w * sizeof(float));
+    DALLOC(b.small, (size_t)K * h * w * sizeof(uint16_t));
+    DALLOC(b.x, (size_t)K * h * w * sizeof(float));
+    DALLOC(b.mn, (size_t)K * sizeof(int)); DALLOC(b.mx, (size_t)K * sizeof(int));
+    DALLOC(b.morph_ws, morph_workspace_bytes(K, h, w));
+    DALLOC(b.finish_ws, finish_workspace_bytes(K, h, w, fh, fw));
     for (int i = 0; i < 2; i++) {
-        TMAT_HIP(hipMalloc((void **)&b.skel[i], (size_t)K * h * w));
-        TMAT_HIP(hipHostMalloc((void **)&b.skel_host[i], (size_t)K * h * w, hipHostMallocDefault));
-        TMAT_HIP(hipMalloc((void **)&b.field[i], (size_t)K * fh * fw * sizeof(float)));
-        TMAT_HIP(hipMalloc((void **)&b.f255[i], (size_t)K * fh * fw * sizeof(float)));
-        TMAT_HIP(hipHostMalloc((void **)&b.f255_host[i], (size_t)K * fh * fw * sizeof(float), hipHostMallocDefault));
+        DALLOC(b.skel[i], (size_t)K * h * w);
+        HALLOC(b.skel_host[i], (size_t)K * h * w);
+        DALLOC(b.field[i], (size_t)K * fh * fw * sizeof(float));
+        DALLOC(b.f255[i], (size_t)K * fh * fw * sizeof(float));
+        HALLOC(b.f255_host[i], (size_t)K * fh * fw * sizeof(float));
     }
     if (thin_dev_supported(h, w)) {
-        TMAT_HIP(hipMalloc(&b.thin_ws, thin_workspace_bytes(K, h, w)));
-        TMAT_HIP(hipMalloc((void **)&b.tie, (size_t)K * h * w * sizeof(uint32_t)));
+        DALLOC(b.thin_ws, thin_workspace_bytes(K, h, w));
+        DALLOC(b.tie, (size_t)K * h * w * sizeof(uint32_t));
         for (int i = 0; i < 2; i++) {
-            TMAT_HIP(hipMalloc((void **)&b.nfg[i], (size_t)K * sizeof(int)));
-            TMAT_HIP(hipHostMalloc((void **)&b.nfg_host[i], (size_t)K * sizeof(int), hipHostMallocDefault));
-            TMAT_HIP(hipHostMalloc((void **)&b.tie_host[i], (size_t)K * h * w * sizeof(uint32_t), hipHostMallocDefault));
+            DALLOC(b.nfg[i], (size_t)K * sizeof(int));
+            HALLOC(b.nfg_host[i], (size_t)K * sizeof(int));
+            HALLOC(b.tie_host[i], (size_t)K * h * w * sizeof(uint32_t));
         }
     }
     if (fh >= 2 && fw >= 2) {
         const size_t nE = dmt_edge_count(fh, fw);
-        TMAT_HIP(hipMalloc(&b.dmt_ws, dmt_workspace_bytes(K, fh, fw)));
+        DALLOC(b.dmt_ws, dmt_workspace_bytes(K, fh, fw));
         for (int i = 0; i < 2; i++) {
-            TMAT_HIP(hipMalloc((void **)&b.dmt_ids[i], (size_t)K * nE * sizeof(int32_t)));
-            TMAT_HIP(hipHostMalloc((void **)&b.dmt_ids_host[i], (size_t)K * nE * sizeof(int32_t), hipHostMallocDefault));
-            TMAT_HIP(hipMalloc((void **)&b.dmt_m[i], (size_t)K * sizeof(int)));
-            TMAT_HIP(hipHostMalloc((void **)&b.dmt_m_host[i], (size_t)K * sizeof(int), hipHostMallocDefault));
+            DALLOC(b.dmt_ids[i], (size_t)K * nE * sizeof(int32_t));
+            HALLOC(b.dmt_ids_host[i], (size_t)K * nE * sizeof(int32_t));
+            DALLOC(b.dmt_m[i], (size_t)K * sizeof(int));
+            HALLOC(b.dmt_m_host[i], (size_t)K * sizeof(int));
         }
     }
     b.fh = fh; b.fw = fw;
     for (int i = 0; i < 2; i++) {
-        TMAT_HIP(hipMalloc((void **)&b.pred[i], (size_t)K * h * w * sizeof(double)));
-        TMAT_HIP(hipHostMalloc((void **)&b.pred_host[i], (size_t)K * h * w * sizeof(double), hipHostMallocDefault));
-        TMAT_HIP(hipMalloc((void **)&b.filt[i], (size_t)K * h * w));
-        TMAT_HIP(hipMalloc((void **)&b.dist[i], (size_t)K * h * w * sizeof(double)));
-        TMAT_HIP(hipHostMalloc((void **)&b.filt_host[i], (size_t)K * h * w, hipHostMallocDefault));
-        TMAT_HIP(hipHostMalloc((void **)&b.dist_host[i], (size_t)K * h * w * sizeof(double), hipHostMallocDefault));
-        TMAT_HIP(hipHostMalloc((void **)&b.conv_host[i], (size_t)K * sizeof(int), hipHostMallocDefault));
+        DALLOC(b.pred[i], (size_t)K * h * w * sizeof(double));
+        HALLOC(b.pred_host[i], (size_t)K * h * w * sizeof(double));
+        DALLOC(b.filt[i], (size_t)K * h * w);
+        DALLOC(b.dist[i], (size_t)K * h * w * sizeof(double));
+        HALLOC(b.filt_host[i], (size_t)K * h * w);
+        HALLOC(b.dist_host[i], (size_t)K * h * w * sizeof(double));
+        HALLOC(b.conv_host[i], (size_t)K * sizeof(int));
         TMAT_HIP(hipEventCreateWithFlags(&b.done[i], hipEventDisableTiming));
     }
+#undef DALLOC
+#undef HALLOC
     b.K = K; b.H = H; b.W = W; b.h = h; b.w = w;
     return TMAT_OK;
 }
@@ -126,6 +131,12 @@ static bool use_one_stream()
     static const bool one = [] { const char *e = getenv("TMAT_STREAMS"); return !(e && atoi(e) == 2); }();
     return one;
 }
+// the tail of a pass (blend, mask filter, EDT, copies) on the second stream: see enqueue_back
+static bool tail_on_side_stream()
+{
+    static const bool side = [] { const char *e = getenv("TMAT_TAIL_STREAM"); return !(e && atoi(e) == 0); }() && use_one_stream();
+    return side;
+}
 static int enqueue_front(Ctx *c, const uint16_t *imgs_dev, int k, int slot, const TileGeom &g)
 {
     PassBuf &b = c->pass;
@@ -142,6 +153,9 @@ static int enqueue_front(Ctx *c, const uint16_t *imgs_dev, int k, int slot, cons
     float *mn = (float *)c->scratch, *mx = mn + k;
     launch_minmax_f32(b.x, k, (size_t)b.h * b.w, mn, mx, s);
     launch_extract_tiles(b.x, mn, k, g, c->patch_in, s);
+    // oversize: the whole network runs HERE and writes the single patch_out, which the blend of the previous pass may still be
+    // reading on the second stream (enqueue_back's own wait on ev_blend comes too late: it is issued after this forward)
+    if (oversize && tail_on_side_stream() && c->blend_pending[slot ^ 1]) TMAT_HIP(hipStreamWaitEvent(s, c->ev_blend[slot ^ 1], 0));
     int rc = oversize ? unet_forward_dev(c, c->patch_in, k * g.tiles_per_img, c->patch_out, s)
                       : unet_down_dev(c, c->patch_in, k * g.tiles_per_img, c->dout[slot], s);
     if (rc) return rc;
@@ -157,7 +171,7 @@ static int enqueue_back(Ctx *c, int k, int slot, const TileGeom &g)
     // of the chip idle -- runs on the second stream, so that the next pass's network follows this pass's network directly on the main
     // stream: 31.28 -> 31.58 images/s (TMAT_TAIL_STREAM=0 keeps everything on the main stream).  patch_out is single: the next up path
     // waits for this pass's blend.  (Round 2 tried the same with a low-priority stream and saw nothing; the second stream has normal priority.)
-    static const bool tail_side = [] { const char *e = getenv("TMAT_TAIL_STREAM"); return !(e && atoi(e) == 0); }() && use_one_stream();
+    const bool tail_side = tail_on_side_stream();
     if (tail_side && c->blend_pending[slot ^ 1]) TMAT_HIP(hipStreamWaitEvent(s, c->ev_blend[slot ^ 1], 0));
     int rc = g.tiles_per_img > c->max_patches ? TMAT_OK : unet_up_dev(c, c->dout[slot], k * g.tiles_per_img, c->patch_out, s);
     if (rc) return rc;

@@ -14,6 +14,7 @@
 // acc = fmaf(x, w, acc), zero padding, optional ReLU on load; pointwise = chain over the input channels in groups of 8
 // in the order 0,4,1,5,2,6,3,7 (lanes 0-31 feed k = 0, lanes 32-63 k = 1 of each MFMA); epilogue fmaf(acc, scale,
 // shift), optional ReLU.  Bit-exact with the unfused path by construction; tests/test_gpu_unet.py compares bits.
+#include "dev_guard.h"
 #include "tmat_internal.h"
 #include "../../include/tmat.h"
 

@@ -24,6 +24,7 @@
 // chain over the 9 taps in (ky, kx) order from +0.0, zero padding, optional ReLU on load; pointwise chain over the
 // input channels in groups of 8 in the order 0,4,1,5,2,6,3,7; epilogue fmaf(acc, scale, shift), optional ReLU; the
 // pooled form: max, then one add).  tests/test_gpu_unet.py compares bits.
+#include "dev_guard.h"
 #include "tmat_internal.h"
 #include "../../include/tmat.h"
 

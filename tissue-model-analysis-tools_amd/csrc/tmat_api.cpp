@@ -311,6 +311,15 @@ static bool conv(Ctx *c, ConvArgs a, hipStream_t st)
     return ok;
 }
 
+// does down block bi (input resolution P / 2 >> bi) run on the wave-specialised fused separable kernel?
+static bool down_block_ws(const Ctx *c, size_t bi)
+{
+    const DownBlock &d = c->down[bi];
+    const int H = (c->patch / 2) >> bi;
+    return c->fused_sep && c->sep_ws && sepconv_ws_supported(H, H, d.cin, d.cout) && sepconv_ws_supported(H, H, d.cout, d.cout) &&
+           ((d.cout / 4) & (d.cout / 4 - 1)) == 0;
+}
+
 // Down path (memory-bound kernels + small pointwise GEMMs): X (n, P, P) -> dout (n, P/16, P/16, f_deep)
 int unet_down_dev(Ctx *c, const float *X, int n, float *dout, hipStream_t s)
 {
@@ -323,8 +332,7 @@ int unet_down_dev(Ctx *c, const float *X, int n, float *dout, hipStream_t s)
     for (size_t bi = 0; bi < c->down.size(); bi++) {
         auto &d = c->down[bi];
         // prev = b0 (n, H, H, cin)
-        if (c->fused_sep && c->sep_ws && sepconv_ws_supported(H, H, d.cin, d.cout) && sepconv_ws_supported(H, H, d.cout, d.cout) &&
-            ((d.cout / 4) & (d.cout / 4 - 1)) == 0) {
+        if (down_block_ws(c, bi)) {
             // wave-specialised fused kernels (sepconv_ws_kernels.hip): depthwise producers + MFMA consumers in one workgroup.
             // bf16x3 mode: the pointwise contraction on the split weights (bf16x6 keeps these layers in f32: three planes do not fit the LDS budget)
             const float *pw0 = d.pw[0], *pw1 = d.pw[1];
@@ -554,19 +562,23 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
     const size_t unit = (size_t)(patch / 2) * (patch / 2) * c->f0;
     const size_t sizes[4] = {unit, unit, 2 * unit, 2 * unit};
     for (int i = 0; i < 4; i++) {
-        if (!hip_ok(hipMalloc((void **)&c->buf[i], sizes[i] * c->max_patches * sizeof(float)), "hipMalloc(activations)")) {
+        c->buf_bytes[i] = sizes[i] * c->max_patches * sizeof(float);
+        if (!hip_ok(hipMalloc((void **)&c->buf[i], c->buf_bytes[i]), "hipMalloc(activations)")) {
             tmat_destroy((tmat_handle)c); return TMAT_E_HIP;
         }
     }
     // up-path buffers: t1 (unit), hoisted residual (unit/4), block outputs alternate (unit/2, unit); down-path output x2
     const size_t usizes[4] = {unit, unit / 4, unit / 2, unit};
-    for (int i = 0; i < 4; i++)
-        if (!hip_ok(hipMalloc((void **)&c->ubuf[i], usizes[i] * c->max_patches * sizeof(float)), "hipMalloc(up buffers)")) {
+    for (int i = 0; i < 4; i++) {
+        c->ubuf_bytes[i] = usizes[i] * c->max_patches * sizeof(float);
+        if (!hip_ok(hipMalloc((void **)&c->ubuf[i], c->ubuf_bytes[i]), "hipMalloc(up buffers)")) {
             tmat_destroy((tmat_handle)c); return TMAT_E_HIP;
         }
+    }
     const size_t dsz = (size_t)(patch >> (1 + c->down.size())) * (patch >> (1 + c->down.size())) * c->up[0].cin;
+    c->dout_bytes = dsz * c->max_patches * sizeof(float);
     for (int i = 0; i < 2; i++)
-        if (!hip_ok(hipMalloc((void **)&c->dout[i], dsz * c->max_patches * sizeof(float)), "hipMalloc(dout)")) {
+        if (!hip_ok(hipMalloc((void **)&c->dout[i], c->dout_bytes), "hipMalloc(dout)")) {
             tmat_destroy((tmat_handle)c); return TMAT_E_HIP;
         }
     if (!hip_ok(hipStreamCreate(&c->stream2), "hipStreamCreate(2)") || !hip_ok(hipStreamCreateWithPriority(&c->stream3, hipStreamDefault, prio_least), "hipStreamCreate(3)")) {
@@ -745,15 +757,47 @@ int tmat_set_precision(tmat_handle h, int mode)
     TMAT_HIP(hipSetDevice(c->device));
     if (mode != TMAT_PRECISION_F32) {
         auto &mp = c->wsplit[mode];
+        // bf16x6 keeps the fused separable layers in f32 (three planes do not fit their LDS budget): no split copy of their pointwise weights
+        std::vector<const float *> skip;
+        if (mode == TMAT_PRECISION_BF16X6)
+            for (size_t bi = 0; bi < c->down.size(); bi++)
+                if (down_block_ws(c, bi)) { skip.push_back(c->down[bi].pw[0]); skip.push_back(c->down[bi].pw[1]); }
         for (auto &kv : c->conv_w_host) {
-            if (mp.count(kv.first)) continue;
+            if (mp.count(kv.first) || std::find(skip.begin(), skip.end(), kv.first) != skip.end()) continue;
             float *dev = nullptr;
             if (!upload(c, split_bf16(kv.second.w, mode + 1), &dev)) return TMAT_E_HIP;
             mp[kv.first] = dev;
         }
     }
-    TMAT_HIP(hipStreamSynchronize(c->stream));
+    { const int rc = tmat_sync(h); if (rc) return rc; }      // all three streams: nothing in flight reads the old mode's weights
     c->precision = mode;
+    return TMAT_OK;
+}
+
+// Test-only (tests/test_gpu_poison.py): fill every scratch workspace of the handle -- the activation ping-pong sets, the pooled-tile
+// strips that live in them, patch_in / patch_out, the scratch block and every per-pass device / pinned buffer -- with `byte_pattern`
+// (0xFF: NaN as f32 / f64, -1 as int).  Weights, the spline window and the Lanczos tables are constants and stay.  A forward or a pass
+// that reads a location it has not written in the same call then produces NaNs or a mismatch against the oracle deterministically,
+// instead of depending on what a recycled allocation happens to hold.
+int tmat_debug_poison(tmat_handle h, int byte_pattern)
+{
+    Ctx *c = (Ctx *)h;
+    if (!c) { set_error("null handle"); return TMAT_E_ARG; }
+    TMAT_HIP(hipSetDevice(c->device));
+    { const int rc = tmat_sync(h); if (rc) return rc; }
+    std::vector<WsEnt> all;
+    for (int i = 0; i < 4; i++) { if (c->buf[i]) all.push_back({c->buf[i], c->buf_bytes[i], false}); if (c->ubuf[i]) all.push_back({c->ubuf[i], c->ubuf_bytes[i], false}); }
+    for (int i = 0; i < 2; i++) if (c->dout[i]) all.push_back({c->dout[i], c->dout_bytes, false});
+    const size_t pio = (size_t)c->patch * c->patch * c->patch_cap * sizeof(float);
+    if (c->patch_in) all.push_back({c->patch_in, pio, false});
+    if (c->patch_out) all.push_back({c->patch_out, pio, false});
+    if (c->scratch) all.push_back({c->scratch, c->scratch_bytes, false});
+    all.insert(all.end(), c->pass.ws.begin(), c->pass.ws.end());
+    for (const WsEnt &e : all) {
+        if (e.host) memset(e.p, byte_pattern, e.bytes);
+        else TMAT_HIP(hipMemsetAsync(e.p, byte_pattern, e.bytes, c->stream));
+    }
+    TMAT_HIP(hipStreamSynchronize(c->stream));
     return TMAT_OK;
 }
 

@@ -24,6 +24,8 @@ struct UpBlock {
     float *res_w = nullptr, *res_b = nullptr;
 };
 struct ProfEv { hipEvent_t e0, e1; double flops; };
+// a device / pinned workspace a forward or a pass writes before it reads (tmat_debug_poison fills exactly these)
+struct WsEnt { void *p; size_t bytes; bool host; };
 struct ConvWHost { std::vector<float> w; int cin; };        // host copy of an MFMA convolution's weights ([rows][cin])
 
 // per-geometry buffers of the batch pipeline (pipeline.cpp)
@@ -63,6 +65,7 @@ struct PassBuf {
     int *dmt_m[2] = {nullptr, nullptr};
     int *dmt_m_host[2] = {nullptr, nullptr};
     hipEvent_t done[2] = {nullptr, nullptr};
+    std::vector<WsEnt> ws;                                  // every scratch allocation above with its size (not the Lanczos tables: they are constants)
 };
 
 // weight container ("TMATW001", tmat_amd/synth.py:pack_weights): tensors by name, pointing into the caller's blob
@@ -110,6 +113,7 @@ struct Ctx {
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_blend[2] = {nullptr, nullptr};      // the tail of a pass (blend, mask filter, EDT) on the second stream
     bool blend_pending[2] = {false, false};
     float *patch_in = nullptr, *patch_out = nullptr;
+    size_t buf_bytes[4] = {0, 0, 0, 0}, ubuf_bytes[4] = {0, 0, 0, 0}, dout_bytes = 0;      // sizes of the activation workspaces (tmat_debug_poison)
     float input_sat = 65535.f;                               // Lanczos saturation: 65535, or 255 for 8-bit sources (tmat_set_input_depth)
     int patch_cap = 0;                                       // patches patch_in / patch_out hold (>= max_patches)
     void *scratch = nullptr;

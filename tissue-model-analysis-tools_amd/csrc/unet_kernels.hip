@@ -11,6 +11,7 @@
 //   such a chain (one rounding per product, k ascending), so the dense 3x3 / 1x1 contractions run on
 //   the matrix cores at full f32 precision.  Epilogues: v = fmaf(acc, scale, shift) (folded BN) or acc + bias,
 //   optional residual add, optional ReLU.  Compiled with -ffp-contract=off.
+#include "dev_guard.h"
 #include "tmat_internal.h"
 #include "../../include/tmat.h"
 

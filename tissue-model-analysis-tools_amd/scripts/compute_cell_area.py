@@ -123,22 +123,28 @@ def main(argv=None):
                 areas[img_id], kept_all[img_id] = a, k
 
     failed = False
-    for i0 in range(0, len(mine), batch_size):
-        group = {}
-        for img_id in mine[i0:i0 + batch_size]:
-            try:
-                if is_stack:
-                    img = zstacks.proj_max(load_stack(paths[img_id], args.channel, args.time), handle=handle)     # compute_cell_area.py:50-52
-                else:
-                    img = load_image_2d(paths[img_id], args.channel, args.time)
-            except (OSError, ValueError) as error:
-                print(f"{FAIL}{error}", flush=True)
-                failed = True               # still enter the gather below: the other ranks are waiting in it
+    try:
+        for i0 in range(0, len(mine), batch_size):
+            group = {}
+            for img_id in mine[i0:i0 + batch_size]:
+                try:
+                    if is_stack:
+                        img = zstacks.proj_max(load_stack(paths[img_id], args.channel, args.time), handle=handle)     # compute_cell_area.py:50-52
+                    else:
+                        img = load_image_2d(paths[img_id], args.channel, args.time)
+                except (OSError, ValueError) as error:
+                    print(f"{FAIL}{error}", flush=True)
+                    failed = True               # still enter the gather below: the other ranks are waiting in it
+                    break
+                group.setdefault((img.shape, img.dtype.str), []).append((img_id, img))
+            if failed:
                 break
-            group.setdefault((img.shape, img.dtype.str), []).append((img_id, img))
-        if failed:
-            break
-        flush(group)
+            flush(group)
+    except Exception:                           # noqa: BLE001 -- a library / HIP error in flush must not leave the other ranks in the gather
+        import traceback
+        traceback.print_exc()
+        print(f"{FAIL}rank {rank}: the shard failed", flush=True)
+        failed = True
     index_of = {img_id: i for i, img_id in enumerate(img_ids)}
     try:
         gathered = distributed.gather_rows([] if failed else [(index_of[i], 0, areas[i], 0.0) for i in mine], n_total=len(img_ids), failed=failed)

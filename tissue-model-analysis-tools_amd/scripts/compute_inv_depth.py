@@ -152,26 +152,32 @@ def main(argv=None):
         pending.clear()
 
     stack_ids = sorted(zstack_paths)              # a deterministic order the ranks agree on (the reference keeps glob order)
-    for si in distributed.shard_indices(len(stack_ids), rank, ws):
-        zstack_id = stack_ids[int(si)]
-        zstack_path = zstack_paths[zstack_id]
-        print(f"Processing {zstack_id}...", flush=True)
-        try:
-            if isinstance(zstack_path, str) and zstack_path.endswith(".npy"):
-                img = np.load(zstack_path)
-            else:
-                img, _ = helper.load_image(zstack_path, args.time, args.channel)
-        except (OSError, ValueError) as error:
-            print(f"{FAIL}{error}", flush=True)
-            failed = True                         # still enter the gather below: the other ranks are waiting in it
-            break
-        if img.ndim == 2:
-            img = img[None]
-        pending.append((int(si), img))
-        if sum(len(im) for _, im in pending) >= 128:
+    try:
+        for si in distributed.shard_indices(len(stack_ids), rank, ws):
+            zstack_id = stack_ids[int(si)]
+            zstack_path = zstack_paths[zstack_id]
+            print(f"Processing {zstack_id}...", flush=True)
+            try:
+                if isinstance(zstack_path, str) and zstack_path.endswith(".npy"):
+                    img = np.load(zstack_path)
+                else:
+                    img, _ = helper.load_image(zstack_path, args.time, args.channel)
+            except (OSError, ValueError) as error:
+                print(f"{FAIL}{error}", flush=True)
+                failed = True                         # still enter the gather below: the other ranks are waiting in it
+                break
+            if img.ndim == 2:
+                img = img[None]
+            pending.append((int(si), img))
+            if sum(len(im) for _, im in pending) >= 128:
+                flush_pending()
+        if not failed:
             flush_pending()
-    if not failed:
-        flush_pending()
+    except Exception:                                 # noqa: BLE001 -- a library / HIP error must not leave the other ranks in the gather
+        import traceback
+        traceback.print_exc()
+        print(f"{FAIL}rank {rank}: the shard failed", flush=True)
+        failed = True
 
     try:
         gathered = distributed.gather_rows_ragged(rows, failed=failed)

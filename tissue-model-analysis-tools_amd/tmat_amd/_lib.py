@@ -81,6 +81,7 @@ def lib():
     L.tmat_resnet_predict.argtypes = [vp, i, vp, i, i, vp]
     L.tmat_inv_depth_predict.argtypes = [vp, vp, i, vp, i, i, i, i, vp, vp]
     L.tmat_prof_enable.argtypes = [vp, i]
+    L.tmat_debug_poison.argtypes = [vp, i]
     L.tmat_set_precision.argtypes = [vp, i]
     L.tmat_set_input_norm.argtypes = [vp, i, C.c_double, C.c_double]
     L.tmat_preprocess_batch.argtypes = [vp, vp, i, i, i, C.c_double, vp]
@@ -101,7 +102,7 @@ EXPORTS = [
     "tmat_predict_smooth", "tmat_segment_batch", "tmat_postprocess_batch", "tmat_filter_edt_batch", "tmat_medial_axis_batch", "tmat_finish_batch", "tmat_filter_mask_batch", "tmat_zproj_batch", "tmat_zproj_dev", "tmat_gather_rows",
     "tmat_dmt_graph", "tmat_morse_stats",
     "tmat_analyze_batch_dev", "tmat_analyze_batch", "tmat_dev_alloc", "tmat_dev_free", "tmat_dev_upload",
-    "tmat_prof_enable", "tmat_prof_read", "tmat_set_precision", "tmat_set_input_norm", "tmat_preprocess_batch", "tmat_well_threshold", "tmat_well_threshold_f64", "tmat_canny_mask", "tmat_host_lanczos4_u16", "tmat_host_rescale01_u16",
+    "tmat_prof_enable", "tmat_prof_read", "tmat_debug_poison", "tmat_set_precision", "tmat_set_input_norm", "tmat_preprocess_batch", "tmat_well_threshold", "tmat_well_threshold_f64", "tmat_canny_mask", "tmat_host_lanczos4_u16", "tmat_host_rescale01_u16",
     "tmat_host_rescale255_f32", "tmat_host_filter_mask", "tmat_host_skeletonize", "tmat_host_medial_axis",
     "tmat_host_permutation", "tmat_host_postprocess",
     "tmat_set_gaussian_table", "tmat_host_gaussian_kernel1d", "tmat_gaussian_f32", "tmat_sato_batch", "tmat_stack_prepare", "tmat_vessel_field",
@@ -235,6 +236,10 @@ class Handle:
         if mode not in modes:
             raise ValueError(f"precision must be one of {sorted(modes)}")
         check(lib().tmat_set_precision(self._h, modes[mode]), "tmat_set_precision")
+
+    def debug_poison(self, byte_pattern=0xFF):
+        """test-only: fill every scratch workspace of the handle with a byte pattern (include/tmat.h:tmat_debug_poison)"""
+        check(lib().tmat_debug_poison(self._h, int(byte_pattern)), "tmat_debug_poison")
 
     def prof_enable(self, on=True):
         check(lib().tmat_prof_enable(self._h, int(on)), "tmat_prof_enable")

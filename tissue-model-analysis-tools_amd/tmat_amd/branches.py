@@ -154,23 +154,32 @@ def run_sharded(ids, load_fn, width_fn, analyze_fn, config: dict, rank: int = 0,
                     results[suffix].append((gidx, r[1], pixels_to_microns(r[2], DOWNSAMPLE_WIDTH, width_um),
                                             pixels_to_microns(r[3], DOWNSAMPLE_WIDTH, width_um)))
 
+    # Whatever goes wrong on this rank -- an unreadable image (InputError), a HIP / library error out of analyze_fn, a shape
+    # surprise in np.stack -- the rank must still enter the collective below: the other ranks are waiting in it and would block
+    # until the launcher kills them.  The failure travels through the gather (distributed.gather_rows raises RankFailed everywhere).
     groups, held, failed = {}, 0, False
-    for gidx in mine:
-        img_id = ids[int(gidx)]
-        log(f"Analyzing {img_id}...")
-        try:
-            img = load_fn(img_id)
-            width_um = width_fn(img_id, img)
-        except InputError:
-            failed = True           # stop working, but still enter the collective below (distributed.gather_rows)
-            break
-        groups.setdefault((img.shape, float(width_um), 8 * img.dtype.itemsize), []).append((int(gidx), img))
-        held += 1
-        if held >= chunk:           # bounded host / HBM footprint: the reference streams one image at a time
+    try:
+        for gidx in mine:
+            img_id = ids[int(gidx)]
+            log(f"Analyzing {img_id}...")
+            try:
+                img = load_fn(img_id)
+                width_um = width_fn(img_id, img)
+            except InputError:
+                failed = True
+                break
+            groups.setdefault((img.shape, float(width_um), 8 * img.dtype.itemsize), []).append((int(gidx), img))
+            held += 1
+            if held >= chunk:           # bounded host / HBM footprint: the reference streams one image at a time
+                flush(groups)
+                groups, held = {}, 0
+        if not failed:
             flush(groups)
-            groups, held = {}, 0
-    if not failed:
-        flush(groups)
+    except Exception:                   # noqa: BLE001 -- reported here, re-raised as RankFailed by the gather on every rank
+        import traceback
+        traceback.print_exc()
+        log(f"rank {rank}: the shard failed (traceback above); entering the gather with the failure marker")
+        failed = True
     return {suffix: distributed.gather_rows(results[suffix], n_total=len(ids), failed=failed) for _, suffix in grid}
 
 
