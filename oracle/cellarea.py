@@ -75,6 +75,43 @@ def resize_linear_u16(img: np.ndarray, out_hw) -> np.ndarray:
     return np.clip(np.rint(out), 0, 65535).astype(np.uint16)
 
 
+def linear_axis_fixed(n_src, n_dst):
+    """cv2's coefficient tables for 8-bit sources (imgproc/src/resize.cpp, resizeGeneric_ with fixed_pt): the float weights of
+    linear_axis scaled by INTER_RESIZE_COEF_SCALE = 2048 and rounded to short with saturate_cast (cvRound: half to even)"""
+    i0, i1, w0, w1 = linear_axis(n_src, n_dst)
+    a0 = np.rint(w0.astype(np.float32) * np.float32(2048)).astype(np.int64)
+    a1 = np.rint(w1.astype(np.float32) * np.float32(2048)).astype(np.int64)
+    return i0, i1, a0, a1
+
+
+def resize_linear_u8(img: np.ndarray, out_hw) -> np.ndarray:
+    """cv2.resize(INTER_LINEAR) on uint8 (OpenCV >= 4.9 < 4.10, setup.py:63; not importable here: published source restated --
+    parity unpinned, hand-derived vectors in tests/test_oracle_cellarea.py).  8-bit images take the FIXED-POINT path: 11-bit
+    coefficients, horizontal pass into int32 (HResizeLinear<uchar, int, short, 2048>: S[c0] a0 + S[c1] a1), vertical pass
+    VResizeLinear<uchar, int, short, FixedPtCast<int, uchar, 22>>'s 8-bit specialisation
+        dst = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2
+    (the form its SIMD lanes evaluate).  An exact halving on both axes is INTER_AREA's integer mean, as for uint16.  IPP's own
+    8-bit linear resize is not used by default (cv::ipp::useIPP_NotExact() is false)."""
+    H, W = img.shape
+    oh, ow = out_hw
+    a = img.astype(np.int64)
+    if H == 2 * oh and W == 2 * ow:
+        return ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    c0, c1, a0, a1 = linear_axis_fixed(W, ow)
+    r0, r1, b0, b1 = linear_axis_fixed(H, oh)
+    rows = a[:, c0] * a0 + a[:, c1] * a1                          # int32 in cv2: at most 255 * 2048
+    out = (((b0[:, None] * (rows[r0] >> 4)) >> 16) + ((b1[:, None] * (rows[r1] >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def resize_linear(img: np.ndarray, out_hw) -> np.ndarray:
+    """cv2.resize(img, dsize) as the config-5 tools call it (bilinear: see resize_linear_u16), by source dtype: uint8 images go
+    through cv2's fixed-point arithmetic, uint16 through its float arithmetic; the result keeps the dtype"""
+    if img.dtype == np.uint8:
+        return resize_linear_u8(img, out_hw)
+    return resize_linear_u16(img.astype(np.uint16), out_hw)
+
+
 def rescale01(img: np.ndarray) -> np.ndarray:
     """rescale_intensity(img, out_range=(0, 1)).astype(float32) for an integer image (compute_cell_area.py:79)"""
     lo, hi = float(img.min()), float(img.max())
@@ -161,7 +198,7 @@ def cell_area(img: np.ndarray, dsamp_size=512, sd_coef=0.0):
     if img.ndim == 3:
         img = img.max(0)
     if dsamp_size is not None:
-        img = resize_linear_u16(img.astype(np.uint16), resized_shape(img.shape, dsamp_size))
+        img = resize_linear(img, resized_shape(img.shape, dsamp_size))
     thresh, kept = gmm_threshold(rescale01(img), sd_coef, levels=img)
     return kept.sum() / kept.size, kept.astype(np.uint8) * 255
 
@@ -173,7 +210,7 @@ def cell_area_well(img: np.ndarray, dsamp_size=512, sd_coef=0.0, seed=0):
     if img.ndim == 3:
         img = img.max(0)
     if dsamp_size is not None:
-        img = resize_linear_u16(img.astype(np.uint16), resized_shape(img.shape, dsamp_size))
+        img = resize_linear(img, resized_shape(img.shape, dsamp_size))
     well = np.asarray(wellmask.generate_well_mask(img, mask_val=255, seed=seed))
     inside = well > 0
     thresh, kept = gmm_threshold(rescale01(img), sd_coef, levels=img, mask=inside)

@@ -39,7 +39,7 @@ def prep_inv_depth_imgs(stack: np.ndarray, size: int = 256) -> np.ndarray:
     from . import cellarea as ca
     out = np.empty((len(stack), size, size, 3), np.float32)
     for z, sl in enumerate(stack):
-        small = ca.resize_linear_u16(sl.astype(np.uint16), (size, size)).astype(np.float64)
+        small = ca.resize_linear(sl, (size, size)).astype(np.float64)           # uint8 slices: cv2's fixed-point path
         lo, hi = small.min(), small.max()
         g = np.clip(small, lo, hi)
         g = ((g - lo) / (hi - lo)) * 255.0 + 0.0 if lo != hi else np.clip(g, 0, 255)

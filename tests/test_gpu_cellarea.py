@@ -158,3 +158,32 @@ def test_exact_halving_takes_cv2s_area_path():
         assert np.array_equal(got[i], ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint16))
         assert np.array_equal(got[i], oc.resize_linear_u16(big[i], (32, 32)))
         assert np.array_equal(odd[i], oc.resize_linear_u16(big[i], oc.resized_shape((64, 64), 40)))
+
+
+def test_eight_bit_sources_take_cv2s_fixed_point_bilinear():
+    """uint8 images: cv2.resize(INTER_LINEAR) is the fixed-point path (11-bit coefficients, (b0 (S0 >> 4) >> 16) + (b1 (S1 >> 4) >> 16) + 2 >> 2),
+    not the float path of uint16 images (oracle/cellarea.py:resize_linear_u8, hand-derived vectors in tests/test_oracle_cellarea.py);
+    reference call site scripts/compute_cell_area.py:54-57.  The device follows the source dtype; the whole tool on uint8 images equals
+    the oracle's, and the two arithmetic paths do differ on the same pixels."""
+    from oracle import cellarea as oc
+    from tmat_amd import _lib, preprocessing
+    rs = np.random.RandomState(12)
+    imgs8 = rs.randint(0, 256, (3, 90, 120)).astype(np.uint8)
+    h = _lib.Handle(None, 0)
+    try:
+        got8 = preprocessing.resize_batch(h, imgs8, 77)                         # 90 x 120 -> 58 x 77
+        got16 = preprocessing.resize_batch(h, imgs8.astype(np.uint16), 77)      # the same pixels as uint16: float path
+        plate = np.stack([_well_plate(3, (300, 320), np.uint8), _well_plate(4, (300, 320), np.uint8)])
+        area, kept = preprocessing.cell_area_batch(h, plate, 200, 0.0)
+        same = preprocessing.resize_batch(h, imgs8.astype(np.uint16), 77)       # the depth is per call: back on the float path
+    finally:
+        h.close()
+    shp = oc.resized_shape((90, 120), 77)
+    for i in range(3):
+        assert np.array_equal(got8[i], oc.resize_linear_u8(imgs8[i], shp))
+        assert np.array_equal(got16[i], oc.resize_linear_u16(imgs8[i].astype(np.uint16), shp))
+    assert (got8 != got16).any() and np.abs(got8.astype(int) - got16.astype(int)).max() == 1
+    assert np.array_equal(same, got16)
+    for i in range(2):
+        a0, k0 = oc.cell_area(plate[i], 200, 0.0)
+        assert area[i] == a0 and np.array_equal(kept[i], k0)

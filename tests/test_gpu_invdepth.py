@@ -66,6 +66,22 @@ def test_exact_halving_of_a_512_slice_takes_cv2s_area_path(plain):
     assert np.array_equal(x.view(np.uint32), ox.view(np.uint32))
 
 
+def test_eight_bit_stacks_take_cv2s_fixed_point_bilinear(plain):
+    """uint8 slices (data_prep.py:36: cv2.resize on the slice as loaded): the fixed-point bilinear path; the prepared input and the
+    probabilities equal the oracle's, and differ from what the same pixels give as uint16"""
+    from oracle import resnet as orr
+    from tmat_amd import inv_depth, synth
+    ens = inv_depth.InvDepthEnsemble(plain, [inv_depth.synth_resnet_weights(0, "conv2_block1_out")])
+    stack16 = synth.synth_stack(5, 2, 300, 360, n_vessels=8)
+    stack8 = (stack16 >> 8).astype(np.uint8)
+    probs, x = ens.predict_stack(stack8, return_input=True)
+    ox = orr.prep_inv_depth_imgs(stack8, 256)
+    assert np.array_equal(x.view(np.uint32), ox.view(np.uint32))
+    _, x16 = ens.predict_stack(stack8.astype(np.uint16), return_input=True)
+    assert np.array_equal(x16.view(np.uint32), orr.prep_inv_depth_imgs(stack8.astype(np.uint16), 256).view(np.uint32))
+    assert (x != x16).any()
+
+
 def test_bad_weights_and_arguments(plain):
     from tmat_amd import _lib, inv_depth
     w = inv_depth.synth_resnet_weights(0, "conv2_block1_out")

@@ -78,11 +78,14 @@ def test_large_launch_race_screen(weights):
 
 
 @pytest.mark.parametrize("env", [{"TMAT_FUSED_POOL": "0"}, {"TMAT_FUSED_SEP": "0"}, {"TMAT_SEP_WS": "0"}, {"TMAT_SEP_WS": "0", "TMAT_FUSED_POOL": "0"},
+                                 {"TMAT_STEM_FUSED": "0"}, {"TMAT_RELU_COPY": "0"}, {"TMAT_STEM_FUSED": "0", "TMAT_RELU_COPY": "0", "TMAT_FUSED_POOL": "0"},
                                  {"TMAT_SEP_WS": "0", "TMAT_SEP_WAVES": "4"}, {"TMAT_SEP_WS": "0", "TMAT_SEP_WAVES": "4", "TMAT_FUSED_POOL": "0"}])
 def test_unfused_down_path_variants_give_the_same_bits(weights, env, monkeypatch):
     """the down path has several forms -- separate depthwise / pointwise / pool kernels, fused depthwise->pointwise (the
     wave-specialised kernel of round 3, the default, or round 2's single-role kernel with TMAT_SEP_WS=0), each with or without
-    the max-pool + residual add behind it -- selected per handle at creation; round 2's kernel also exists with 4-wave
+    the max-pool + residual add behind it, the stem recomputed inside the first separable convolution (round 4, default) or written
+    by its own kernel (TMAT_STEM_FUSED=0), activated copies of the block outputs (default) or ReLU on load (TMAT_RELU_COPY=0)
+    -- selected per handle at creation; round 2's kernel also exists with 4-wave
     workgroups (two per CU, 8 x 16 pixel tiles; read once per process, so these cases run in a child process); all must
     equal the oracle"""
     from oracle import unet as ou

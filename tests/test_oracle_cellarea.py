@@ -82,6 +82,63 @@ def test_resize_linear_against_scipy_map_coordinates():
     assert ca.resized_shape((1000, 1500), 512) == (512, 341)            # dsize (341, 512) is read as (width, height)
 
 
+def _cv2_linear_8u_scalar(img, oh, ow):
+    """cv2's 8-bit INTER_LINEAR written out pixel by pixel from the published source (imgproc/src/resize.cpp: resizeGeneric_ tables,
+    HResizeLinear<uchar, int, short, 2048>, the 8-bit VResizeLinear), independent of the vectorised oracle function"""
+    import math
+    H, W = img.shape
+
+    def axis(n_src, n_dst):
+        tab = []
+        scale = n_src / n_dst
+        for d in range(n_dst):
+            fx = np.float32((d + 0.5) * scale - 0.5)
+            sx = int(math.floor(fx))
+            fx = np.float32(fx - sx)
+            if sx < 0:
+                sx, fx = 0, np.float32(0)
+            if sx >= n_src - 1:
+                sx, fx = n_src - 1, np.float32(0)
+            a0 = int(np.rint(np.float32((np.float32(1) - fx) * np.float32(2048))))       # saturate_cast<short>(cbuf[k] * INTER_RESIZE_COEF_SCALE)
+            a1 = int(np.rint(np.float32(fx * np.float32(2048))))
+            tab.append((sx, min(sx + 1, n_src - 1), a0, a1))
+        return tab
+    xs, ys = axis(W, ow), axis(H, oh)
+    out = np.zeros((oh, ow), np.uint8)
+    for y, (r0, r1, b0, b1) in enumerate(ys):
+        for x, (c0, c1, a0, a1) in enumerate(xs):
+            s0 = int(img[r0, c0]) * a0 + int(img[r0, c1]) * a1
+            s1 = int(img[r1, c0]) * a0 + int(img[r1, c1]) * a1
+            out[y, x] = (((b0 * (s0 >> 4)) >> 16) + ((b1 * (s1 >> 4)) >> 16) + 2) >> 2
+    return out
+
+
+def test_resize_linear_u8_is_cv2s_fixed_point_arithmetic():
+    """PARITY UNPINNED vs cv2 (absent; opencv-python >= 4.9, setup.py:63).  uint8 images go through cv2's fixed-point bilinear path
+    (reference call sites scripts/compute_cell_area.py:54-57, data_prep.py:36).  Pinned to (1) a hand-derived vector, (2) an
+    independent pixel-by-pixel restatement of the published source, (3) the properties the arithmetic must have: identity at equal
+    size, INTER_AREA's integer mean for an exact halving, at most 1 level from the float path -- and NOT equal to it everywhere."""
+    img = np.array([[10, 20], [30, 250]], np.uint8)
+    # 2 x 2 -> 3 x 3 (scale 2/3): source coordinates -1/6 (clamped: weights 2048, 0), 1/2 (1024, 1024), 7/6 (clamped to the last pixel).
+    # horizontal sums: row 0: 20480, 30720, 40960; row 1: 61440, 286720, 512000.  Centre: ((1024 * (30720 >> 4)) >> 16) = 30,
+    # ((1024 * (286720 >> 4)) >> 16) = 280, (30 + 280 + 2) >> 2 = 78; edge rows / columns reproduce the source pixels.
+    want = np.array([[10, 15, 20], [20, 78, 135], [30, 140, 250]], np.uint8)
+    assert np.array_equal(ca.resize_linear_u8(img, (3, 3)), want)
+    rs = np.random.RandomState(8)
+    big = rs.randint(0, 256, (37, 41)).astype(np.uint8)
+    for oh, ow in ((23, 29), (37, 41), (50, 64), (5, 3)):
+        got = ca.resize_linear_u8(big, (oh, ow))
+        assert got.dtype == np.uint8 and np.array_equal(got, _cv2_linear_8u_scalar(big, oh, ow)), (oh, ow)
+    assert np.array_equal(ca.resize_linear_u8(big, (37, 41)), big)                      # equal size: identity
+    even = rs.randint(0, 256, (16, 24)).astype(np.uint8)
+    a = even.astype(np.int64)
+    assert np.array_equal(ca.resize_linear_u8(even, (8, 12)), ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8))
+    f = ca.resize_linear_u16(big.astype(np.uint16), (23, 29)).astype(np.int64)          # what the float path would give
+    d = ca.resize_linear_u8(big, (23, 29)).astype(np.int64) - f
+    assert np.abs(d).max() == 1 and (d != 0).mean() < 0.2                              # the two paths differ, by one level, at a few pixels
+    assert ca.resize_linear(big, (23, 29)).dtype == np.uint8 and ca.resize_linear(big.astype(np.uint16), (23, 29)).dtype == np.uint16
+
+
 def test_cell_area_of_a_stack_uses_the_max_projection():
     rs = np.random.RandomState(1)
     st = (rs.uniform(0, 1, (3, 40, 40)) ** 6 * 60000).astype(np.uint16)

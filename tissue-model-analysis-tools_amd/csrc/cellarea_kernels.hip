@@ -11,6 +11,7 @@
 #include "tmat_ctx.h"
 
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 namespace tmat {
@@ -28,6 +29,27 @@ __global__ __launch_bounds__(256) void resize_linear_u16_kernel(const uint16_t *
         const float b = (float)src[(size_t)r1[y] * W + c0[x]] * wc0[x] + (float)src[(size_t)r1[y] * W + c1[x]] * wc1[x];
         const float v = rintf(a * wr0[y] + b * wr1[y]);
         out[(size_t)blockIdx.y * oh * ow + p] = (uint16_t)fminf(fmaxf(v, 0.f), 65535.f);
+    }
+}
+
+// cv2.resize(INTER_LINEAR) of uint8 images (widened to uint16 by the caller: values <= 255): OpenCV's FIXED-POINT path
+// (imgproc/src/resize.cpp, resizeGeneric_ with fixed_pt for 8U): 11-bit coefficients a = cvRound(w * 2048) as short; horizontal pass
+// into int32, S[c0] a0 + S[c1] a1; vertical pass of the 8-bit specialisation of VResizeLinear (what its SIMD lanes evaluate):
+//     dst = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.
+// Reference call sites: scripts/compute_cell_area.py:54-57, fl_tissue_model_tools/data_prep.py:36 (cv2 is absent here: parity unpinned;
+// oracle/cellarea.py:resize_linear_u8 restates the same source and tests/test_oracle_cellarea.py holds hand-derived vectors).
+__global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint16_t *__restrict__ img, int H, int W, int oh, int ow, const int *__restrict__ r0,
+                                                               const int *__restrict__ r1, const int *__restrict__ b0, const int *__restrict__ b1,
+                                                               const int *__restrict__ c0, const int *__restrict__ c1, const int *__restrict__ a0,
+                                                               const int *__restrict__ a1, uint16_t *__restrict__ out)
+{
+    const uint16_t *src = img + (size_t)blockIdx.y * H * W;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < oh * ow; p += gridDim.x * 256) {
+        const int y = p / ow, x = p - y * ow;
+        const int h0 = (int)src[(size_t)r0[y] * W + c0[x]] * a0[x] + (int)src[(size_t)r0[y] * W + c1[x]] * a1[x];
+        const int h1 = (int)src[(size_t)r1[y] * W + c0[x]] * a0[x] + (int)src[(size_t)r1[y] * W + c1[x]] * a1[x];
+        const int v = (((b0[y] * (h0 >> 4)) >> 16) + ((b1[y] * (h1 >> 4)) >> 16) + 2) >> 2;
+        out[(size_t)blockIdx.y * oh * ow + p] = (uint16_t)(v < 0 ? 0 : v > 255 ? 255 : v);
     }
 }
 
@@ -258,6 +280,45 @@ static void linear_axis(int n_src, int n_dst, std::vector<int> &i0, std::vector<
     }
 }
 
+// cv2.resize(img, dsize) of the config-5 tools (bilinear, see the kernels) for n images already on the device: uploads the coefficient
+// tables into `tab` ((oh + ow) * 4 dwords, device; must stay allocated until the stream has run the kernel) and launches the arithmetic of
+// the SOURCE depth -- eight_bit: cv2's fixed-point path (tmat_set_input_depth(h, 8)), else the float path; an exact halving on both axes
+// is INTER_AREA's integer mean for both depths.  Also used by tmat_inv_depth_predict (resnet_kernels.hip).
+int launch_resize_linear_dev(const uint16_t *din, int n, int H, int W, int oh, int ow, bool eight_bit, int *tab, uint16_t *dsm, hipStream_t s)
+{
+    const int blocks = (oh * ow + 255) / 256;
+    const dim3 grid(blocks < 1024 ? blocks : 1024, n);
+    if (H == 2 * oh && W == 2 * ow) {
+        hipLaunchKernelGGL(resize_area2_u16_kernel, grid, dim3(256), 0, s, din, H, W, dsm);
+        return 0;
+    }
+    std::vector<int> r0, r1, c0, c1;
+    std::vector<float> wr0, wr1, wc0, wc1;
+    linear_axis(H, oh, r0, r1, wr0, wr1);
+    linear_axis(W, ow, c0, c1, wc0, wc1);
+    // one host block [r0 | r1 | c0 | c1 | wr0 | wr1 | wc0 | wc1]; eight_bit: the weights as cvRound(w * 2048) integers (saturate_cast<short>)
+    std::vector<int> host((size_t)(oh + ow) * 4);
+    int *hr0 = host.data(), *hr1 = hr0 + oh, *hc0 = hr1 + oh, *hc1 = hc0 + ow, *hw = hc1 + ow;
+    for (int i = 0; i < oh; i++) { hr0[i] = r0[i]; hr1[i] = r1[i]; }
+    for (int i = 0; i < ow; i++) { hc0[i] = c0[i]; hc1[i] = c1[i]; }
+    auto put = [&](int *dst, const std::vector<float> &w) {
+        for (size_t i = 0; i < w.size(); i++) {
+            if (eight_bit) dst[i] = (int)std::nearbyint(w[i] * 2048.0f);        // exact product (power of two), round half to even
+            else memcpy(&dst[i], &w[i], 4);
+        }
+    };
+    put(hw, wr0); put(hw + oh, wr1); put(hw + 2 * oh, wc0); put(hw + 2 * oh + ow, wc1);
+    // synchronous copy: `host` goes out of scope at return
+    if (hipMemcpy(tab, host.data(), host.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { set_error("resize: table upload failed"); return -2; }
+    const int *dr0 = tab, *dr1 = dr0 + oh, *dc0 = dr1 + oh, *dc1 = dc0 + ow, *dw = dc1 + ow;
+    if (eight_bit)
+        hipLaunchKernelGGL(resize_linear_u8_kernel, grid, dim3(256), 0, s, din, H, W, oh, ow, dr0, dr1, dw, dw + oh, dc0, dc1, dw + 2 * oh, dw + 2 * oh + ow, dsm);
+    else
+        hipLaunchKernelGGL(resize_linear_u16_kernel, grid, dim3(256), 0, s, din, H, W, oh, ow, dr0, dr1, (const float *)dw, (const float *)(dw + oh), dc0, dc1,
+                           (const float *)(dw + 2 * oh), (const float *)(dw + 2 * oh + ow), dsm);
+    return 0;
+}
+
 }  // namespace tmat
 
 using namespace tmat;
@@ -284,7 +345,6 @@ static int cell_area_impl(tmat_handle hd, const uint16_t *imgs, int n, int H, in
     double *dpar = nullptr;
     uint8_t *dthr = nullptr;
     int *itab = nullptr;
-    float *ftab = nullptr;
     int rc = TMAT_OK;
     auto fail = [&](int code) { rc = code; };
     if (!hip_ok(hipMalloc((void **)&din, nin * 2), "hipMalloc") || !hip_ok(hipMalloc((void **)&hist, (size_t)n * 65536 * 4), "hipMalloc") ||
@@ -292,31 +352,11 @@ static int cell_area_impl(tmat_handle hd, const uint16_t *imgs, int n, int H, in
         (thresholded && !hip_ok(hipMalloc((void **)&dthr, nout), "hipMalloc"))) fail(TMAT_E_HIP);
     if (!rc && !hip_ok(hipMemcpyAsync(din, imgs, nin * 2, hipMemcpyHostToDevice, s), "H2D")) fail(TMAT_E_HIP);
     const uint16_t *small = din;
-    std::vector<int> r0, r1, c0, c1;
-    std::vector<float> wr0, wr1, wc0, wc1;
     if (!rc && out_h) {
-        linear_axis(H, oh, r0, r1, wr0, wr1);
-        linear_axis(W, ow, c0, c1, wc0, wc1);
-        if (!hip_ok(hipMalloc((void **)&dsm, nout * 2), "hipMalloc") || !hip_ok(hipMalloc((void **)&itab, (size_t)(oh + ow) * 2 * 4), "hipMalloc") ||
-            !hip_ok(hipMalloc((void **)&ftab, (size_t)(oh + ow) * 2 * 4), "hipMalloc")) fail(TMAT_E_HIP);
-        if (!rc) {
-            int *dr0 = itab, *dr1 = dr0 + oh, *dc0 = dr1 + oh, *dc1 = dc0 + ow;
-            float *dwr0 = ftab, *dwr1 = dwr0 + oh, *dwc0 = dwr1 + oh, *dwc1 = dwc0 + ow;
-            bool ok = hipMemcpyAsync(dr0, r0.data(), oh * 4, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(dr1, r1.data(), oh * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
-                      hipMemcpyAsync(dc0, c0.data(), ow * 4, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(dc1, c1.data(), ow * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
-                      hipMemcpyAsync(dwr0, wr0.data(), oh * 4, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(dwr1, wr1.data(), oh * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
-                      hipMemcpyAsync(dwc0, wc0.data(), ow * 4, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(dwc1, wc1.data(), ow * 4, hipMemcpyHostToDevice, s) == hipSuccess;
-            if (!ok) { set_error("tmat_cell_area_batch: table upload failed"); fail(TMAT_E_HIP); }
-            else {
-                const int blocks = (oh * ow + 255) / 256;
-                if (H == 2 * oh && W == 2 * ow)
-                    hipLaunchKernelGGL(resize_area2_u16_kernel, dim3(blocks < 1024 ? blocks : 1024, n), dim3(256), 0, s, din, H, W, dsm);
-                else
-                    hipLaunchKernelGGL(resize_linear_u16_kernel, dim3(blocks < 1024 ? blocks : 1024, n), dim3(256), 0, s, din, H, W, oh, ow, dr0, dr1, dwr0, dwr1, dc0, dc1,
-                                       dwc0, dwc1, dsm);
-                small = dsm;
-            }
-        }
+        if (!hip_ok(hipMalloc((void **)&dsm, nout * 2), "hipMalloc") || !hip_ok(hipMalloc((void **)&itab, (size_t)(oh + ow) * 4 * 4), "hipMalloc")) fail(TMAT_E_HIP);
+        // 8-bit sources (tmat_set_input_depth(h, 8)) take cv2's fixed-point arithmetic
+        else if (launch_resize_linear_dev(din, n, H, W, oh, ow, c->input_sat == 255.f, itab, dsm, s)) fail(TMAT_E_HIP);
+        else small = dsm;
     }
     if (!rc && !fit) {          // tmat_resize_linear_u16: only the down-sampled images are wanted
         if (!hip_ok(hipGetLastError(), "launch") || !hip_ok(hipMemcpyAsync(small_out, small, nout * 2, hipMemcpyDeviceToHost, s), "D2H") ||
@@ -356,7 +396,7 @@ static int cell_area_impl(tmat_handle hd, const uint16_t *imgs, int n, int H, in
             }
         }
     }
-    hipFree(din); hipFree(dsm); hipFree(hist); hipFree(kept); hipFree(dpar); hipFree(dthr); hipFree(itab); hipFree(ftab); hipFree(dmaskbuf); hipFree(lohibuf);
+    hipFree(din); hipFree(dsm); hipFree(hist); hipFree(kept); hipFree(dpar); hipFree(dthr); hipFree(itab); hipFree(dmaskbuf); hipFree(lohibuf);
     return rc;
 }
 

@@ -218,23 +218,7 @@ static int resnet_forward_dev(const ResNetModel &m, const float *x, int N, int S
     return hipGetLastError() == hipSuccess ? TMAT_OK : TMAT_E_HIP;
 }
 
-static void linear_axis_f(int n_src, int n_dst, std::vector<int> &i0, std::vector<int> &i1, std::vector<float> &w0, std::vector<float> &w1)
-{
-    const double scale = (double)n_src / (double)n_dst;
-    i0.resize(n_dst); i1.resize(n_dst); w0.resize(n_dst); w1.resize(n_dst);
-    for (int d = 0; d < n_dst; d++) {
-        float fx = (float)(((double)d + 0.5) * scale - 0.5);
-        int sx = (int)std::floor(fx);
-        fx = fx - (float)sx;
-        if (sx < 0) { sx = 0; fx = 0.f; }
-        if (sx >= n_src - 1) { sx = n_src - 1; fx = 0.f; }
-        i0[d] = sx; i1[d] = sx + 1 < n_src ? sx + 1 : n_src - 1;
-        w0[d] = 1.0f - fx; w1[d] = fx;
-    }
-}
-__global__ void resize_linear_u16_kernel(const uint16_t *img, int H, int W, int oh, int ow, const int *r0, const int *r1, const float *wr0, const float *wr1,
-                                         const int *c0, const int *c1, const float *wc0, const float *wc1, uint16_t *out);      // cellarea_kernels.hip
-__global__ void resize_area2_u16_kernel(const uint16_t *img, int H, int W, uint16_t *out);                                      // cellarea_kernels.hip
+int launch_resize_linear_dev(const uint16_t *din, int n, int H, int W, int oh, int ow, bool eight_bit, int *tab, uint16_t *dsm, hipStream_t s);      // cellarea_kernels.hip
 
 }  // namespace tmat
 
@@ -319,35 +303,23 @@ int tmat_inv_depth_predict(tmat_handle hd, const int *model_ids, int n_models, c
     const size_t npx = (size_t)size * size;
     uint16_t *din = nullptr, *dsm = nullptr;
     int *itab = nullptr, *mnmx = nullptr;
-    float *ftab = nullptr, *dx = nullptr, *dp = nullptr, *bufs[4] = {nullptr, nullptr, nullptr, nullptr};
-    std::vector<int> r0, r1, c0, c1;
-    std::vector<float> wr0, wr1, wc0, wc1;
+    float *dx = nullptr, *dp = nullptr, *bufs[4] = {nullptr, nullptr, nullptr, nullptr};
     // cv2.resize(img, img_hw, cv2.INTER_LANCZOS4) (data_prep.py:36): the third positional parameter is `dst`: bilinear
-    linear_axis_f(H, size, r0, r1, wr0, wr1);
-    linear_axis_f(W, size, c0, c1, wc0, wc1);
     int rc = TMAT_OK;
     const int nb = std::min(Z, CH);
     if (!hip_ok(hipMalloc((void **)&din, (size_t)Z * H * W * 2), "hipMalloc") || !hip_ok(hipMalloc((void **)&dsm, (size_t)Z * npx * 2), "hipMalloc") ||
-        !hip_ok(hipMalloc((void **)&itab, (size_t)size * 4 * 4), "hipMalloc") || !hip_ok(hipMalloc((void **)&ftab, (size_t)size * 4 * 4), "hipMalloc") ||
+        !hip_ok(hipMalloc((void **)&itab, (size_t)size * 2 * 4 * 4), "hipMalloc") ||
         !hip_ok(hipMalloc((void **)&mnmx, (size_t)Z * 2 * 4), "hipMalloc") || !hip_ok(hipMalloc((void **)&dx, (size_t)Z * npx * 3 * 4), "hipMalloc") ||
         !hip_ok(hipMalloc((void **)&dp, (size_t)Z * n_models * 4), "hipMalloc")) rc = TMAT_E_HIP;
     for (int i = 0; i < 4 && !rc; i++) if (!hip_ok(hipMalloc((void **)&bufs[i], (size_t)nb * (size / 2) * (size / 2) * 64 * 4), "hipMalloc")) rc = TMAT_E_HIP;
     if (!rc) {
-        int *dr0 = itab, *dr1 = dr0 + size, *dc0 = dr1 + size, *dc1 = dc0 + size;
-        float *dwr0 = ftab, *dwr1 = dwr0 + size, *dwc0 = dwr1 + size, *dwc1 = dwc0 + size;
+        // cv::resize takes INTER_AREA's integer mean for an exact halving on both axes (a 512 x 512 slice at the configured 256 x 256);
+        // 8-bit sources (tmat_set_input_depth(h, 8)) take its fixed-point bilinear arithmetic
         bool ok = hipMemcpyAsync(din, stack, (size_t)Z * H * W * 2, hipMemcpyHostToDevice, s) == hipSuccess &&
-                  hipMemcpyAsync(dr0, r0.data(), size * 4, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(dr1, r1.data(), size * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
-                  hipMemcpyAsync(dc0, c0.data(), size * 4, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(dc1, c1.data(), size * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
-                  hipMemcpyAsync(dwr0, wr0.data(), size * 4, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(dwr1, wr1.data(), size * 4, hipMemcpyHostToDevice, s) == hipSuccess &&
-                  hipMemcpyAsync(dwc0, wc0.data(), size * 4, hipMemcpyHostToDevice, s) == hipSuccess && hipMemcpyAsync(dwc1, wc1.data(), size * 4, hipMemcpyHostToDevice, s) == hipSuccess;
+                  launch_resize_linear_dev(din, Z, H, W, size, size, c->input_sat == 255.f, itab, dsm, s) == 0;
         if (!ok) { set_error("tmat_inv_depth_predict: upload failed"); rc = TMAT_E_HIP; }
         else {
             const int blocks = (int)((npx + 255) / 256);
-            // cv::resize takes INTER_AREA's integer mean for an exact halving on both axes (a 512 x 512 slice at the configured 256 x 256)
-            if (H == 2 * size && W == 2 * size)
-                hipLaunchKernelGGL(resize_area2_u16_kernel, dim3(blocks < 1024 ? blocks : 1024, Z), dim3(256), 0, s, din, H, W, dsm);
-            else
-                hipLaunchKernelGGL(resize_linear_u16_kernel, dim3(blocks < 1024 ? blocks : 1024, Z), dim3(256), 0, s, din, H, W, size, size, dr0, dr1, dwr0, dwr1, dc0, dc1, dwc0, dwc1, dsm);
             hipLaunchKernelGGL(minmax_u16_img_kernel, dim3(Z), dim3(256), 0, s, dsm, (int)npx, mnmx, mnmx + Z);
             hipLaunchKernelGGL(inv_prep_kernel, dim3(blocks < 1024 ? blocks : 1024, Z), dim3(256), 0, s, dsm, (int)npx, mnmx, mnmx + Z, dx);
             for (int mi = 0; mi < n_models && !rc; mi++)
@@ -362,7 +334,7 @@ int tmat_inv_depth_predict(tmat_handle hd, const int *model_ids, int n_models, c
             if (!rc) for (int z = 0; z < Z; z++) for (int mi = 0; mi < n_models; mi++) probs[(size_t)z * n_models + mi] = ph[(size_t)mi * Z + z];     // (Z, n_models)
         }
     }
-    hipFree(din); hipFree(dsm); hipFree(itab); hipFree(ftab); hipFree(mnmx); hipFree(dx); hipFree(dp);
+    hipFree(din); hipFree(dsm); hipFree(itab); hipFree(mnmx); hipFree(dx); hipFree(dp);
     for (float *b : bufs) hipFree(b);
     return rc;
 }

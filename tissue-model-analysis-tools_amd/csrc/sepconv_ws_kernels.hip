@@ -43,6 +43,9 @@ constexpr int WS_A = 256 * 32, WS_X = 1024, WS_B = 128 * 32, WS_NHP = 13, WS_HP 
 constexpr int WS_A0 = 0, WS_A1 = WS_A + WS_X, WS_B0 = WS_A1 + WS_A, WS_B1 = WS_B0 + WS_B, WS_H = WS_B1 + WS_B;
 constexpr int WS_TOTAL = WS_H + 4 * WS_HP;          // 38 912 floats = 152 KiB
 static_assert(WS_TOTAL * 4 <= 160 * 1024, "LDS budget");
+// STEM form: behind the halos, per producer the 21 x 22 window of the single-channel patch its 10 x 10 stem-output halo is computed from
+constexpr int WS_WPITCH = 22, WS_WP = 21 * WS_WPITCH, WS_NWP = (WS_WP + 63) / 64, WS_WIN = WS_TOTAL, WS_TOTAL_STEM = WS_WIN + 4 * WS_NWP * 64;
+static_assert(WS_TOTAL_STEM * 4 <= 160 * 1024, "LDS budget (stem form)");
 static_assert(8 * 9 * 128 <= WS_A + WS_X, "exchange buffer fits an A stage + gap");
 
 struct WsArgs {
@@ -55,6 +58,7 @@ struct WsArgs {
     float *out;           // (N, H, W, Cout); POOL: (N, H/2, W/2, Cout), see sepconv_kernels.hip:SepArgs
     const float *resid;   // POOL only
     float *strip_h, *strip_v, *corner;      // POOL only (pool_fix_add_kernel finishes the tile edges)
+    const float *stem_w, *stem_scale, *stem_shift;      // STEM only: `in` is then the (N, 2H, 2W) single-channel patch; taps [9][Cin], folded BN
 };
 
 __device__ __forceinline__ int ws_pixmap_y(int r) { return ((r >= 4 && r < 12) || (r >= 16 && r < 20) || r >= 28) ? 1 : 0; }
@@ -81,10 +85,17 @@ __device__ long long ws_tl[12 * 2 * 14];         // absolute stamps of workgroup
 // POINTWISE contraction only: the depthwise values stay f32 (producers unchanged, A operand f32 in LDS) and are split into bf16 hi / lo in
 // the consumers' registers; a.pwk then points to the host-split weights, two bf16 planes [plane][Cout][Cin]; three
 // v_mfma_f32_32x32x16_bf16 (lo hi, hi lo, hi hi) replace eight f32 MFMAs.  Same accumulator layout, same epilogues.
-template <bool RELU_IN, bool POOL, int PREC = 0>
+//
+// STEM (round 4): the layer's input is the stem's output, relu(bn(conv3x3 / stride 2 (x))) of the single-channel patch x (models.py:119-121),
+// and is NOT read from memory: every producer recomputes its 10 x 10 halo of the step's 32 channels from a 21 x 22 window of x (LDS-DMA,
+// once per tile) in the vector phase, with stem_kernel's own chain (taps (ky, kx) from +0.0, fmaf(acc, scale, shift), max with 0), and
+// writes it where the LDS-DMA of the plain form would have put it.  The stem tensor (10.5 GB per pass of 1600 patches) is then neither
+// written nor read: 9 multiply-adds per value are cheaper than 8 bytes of HBM traffic.  Halo pixels outside the image are the depthwise
+// convolution's zero padding (zeros, not stem values).
+template <bool RELU_IN, bool POOL, int PREC = 0, bool STEM = false>
 __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, int nNt, int G)
 {
-    __shared__ __attribute__((aligned(16))) float smem[WS_TOTAL];
+    __shared__ __attribute__((aligned(16))) float smem[STEM ? WS_TOTAL_STEM : WS_TOTAL];
 
     // persistent ranges as in sepconv_mfma_kernel: an XCD gets a contiguous super-range of the (pixel tile, channel tile) pairs
     const int b = blockIdx.x;
@@ -101,6 +112,14 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
     const int total = (j1 - j0) * nchunks;                   // steps of this workgroup
     constexpr unsigned OOB = 0x80000000u;
 
+    if (STEM) {
+        // the depthwise taps [9][Cin] (Cin <= 113: launch check) go to the gap X once per workgroup: the producers read their quad's taps from
+        // there at the start of every depthwise phase instead of holding them in 36 registers across the stem phase (whose own 44 weight
+        // registers are dead by then) -- with both sets live the kernel spilled
+        for (int e = t; e < 9 * Cin; e += 768) smem[WS_A + e] = a.dw9[e];
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        WS_BAR()
+    }
     if (wave >= 8) {
         // ================================ producer ================================
         const int p = wave - 8;
@@ -142,32 +161,87 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
             m_left |= (unsigned)(hx == 0) << i; m_right |= (unsigned)(hx == 9) << i;
             m_inv |= (unsigned)(hp >= 100) << i;
         }
+        // STEM: the window of the patch.  Piece i of its WS_NWP LDS-DMA pieces carries window elements 64 i + lane (element e = row e / 22,
+        // column e % 22 of the 21 x 22 window whose first element is patch pixel (2 Y0, 2 X0)), 4 bytes per lane.  A halo at the image border
+        // reaches 2 patch rows / columns past the patch on that side (window rows 0-1 resp. 18-20, columns 0-1 resp. 18-21): those lanes are
+        // redirected out of range like the halo pieces of the plain form (their halo pixels are zero padding anyway).
+        unsigned badw = 0;
+        unsigned w_top = 0, w_bot = 0, w_left = 0, w_right = 0, w_inv = 0;
+        unsigned badm = 0;                                   // STEM: bit i = halo piece i of this lane lies outside the image (zero padding)
+        float *Wp = smem + WS_WIN + p * (WS_NWP * 64);
+        if (STEM) {
+#pragma unroll
+            for (int i = 0; i < WS_NWP; i++) {
+                const int e = 64 * i + lane;
+                const int wy = e / WS_WPITCH, wx = e - wy * WS_WPITCH;
+                w_top |= (unsigned)(wy < 2) << i; w_bot |= (unsigned)(wy >= 18) << i;
+                w_left |= (unsigned)(wx < 2) << i; w_right |= (unsigned)(wx >= 18) << i;
+                w_inv |= (unsigned)(e >= WS_WP) << i;
+            }
+        }
         const float *hA = a.in;
         auto tile_setup = [&](int jj) {
             const int mt = jj / nNt;
             const int n = mt / TPP, tr = mt - n * TPP;
             const int Y0 = (tr / TW) * 16 + oy - 1, X0 = (tr % TW) * 16 + ox - 1;      // image position of the halo's first pixel
-            hA = a.in + ((long)n * a.H * a.W + (long)Y0 * a.W + X0) * Cin;             // may lie before the tensor for border tiles: those lanes are masked
             const unsigned bad = m_inv | (Y0 < 0 ? m_top : 0u) | (Y0 + 9 >= a.H ? m_bot : 0u) | (X0 < 0 ? m_left : 0u) | (X0 + 9 >= a.W ? m_right : 0u);
+            if (STEM) {
+                hA = a.in + ((long)n * a.H * a.W * 4 + (long)(2 * Y0) * (2 * a.W) + 2 * X0);       // may lie before the tensor for border tiles: those lanes are masked
+                badw = w_inv | (Y0 < 0 ? w_top : 0u) | (Y0 + 9 >= a.H ? w_bot : 0u) | (X0 < 0 ? w_left : 0u) | (X0 + 9 >= a.W ? w_right : 0u);
+                badm = bad;
+            } else {
+                hA = a.in + ((long)n * a.H * a.W + (long)Y0 * a.W + X0) * Cin;             // may lie before the tensor for border tiles: those lanes are masked
 #pragma unroll
-            for (int i = 0; i < WS_NHP; i++) hv[i] = ((bad >> i) & 1u) ? OOB : rel[i];
+                for (int i = 0; i < WS_NHP; i++) hv[i] = ((bad >> i) & 1u) ? OOB : rel[i];
+            }
         };
         int hj = j0, hc = 0;                                 // next halo to load: (pair, chunk)
         auto issue_halo = [&]() {
             const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)hA, 0, 0x7fffffff, 0x00020000);
+            if (STEM) {
+                if (hc == 0) {          // a new tile: its window (both chunks of the tile are computed from it)
+                    // the per-lane offsets are recomputed here, once per tile, from a lane id the compiler cannot see through: as loop
+                    // invariants they would sit in 8 registers for the whole kernel (which then spills)
+                    int lane_o = lane;
+                    asm volatile("" : "+v"(lane_o));
 #pragma unroll
-            for (int i = 0; i < WS_NHP; i++)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t *)(Hp + i * 256), 16, hv[i], hc * 128, 0, 0);
+                    for (int i = 0; i < WS_NWP; i++) {
+                        const int e = 64 * i + lane_o;
+                        const int wy = e / WS_WPITCH, wx = e - wy * WS_WPITCH;
+                        const unsigned relw = (unsigned)(wy * 2 * a.W + wx) * 4u;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t *)(Wp + i * 64), 4, ((badw >> i) & 1u) ? OOB : relw, 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < WS_NHP; i++)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t *)(Hp + i * 256), 16, hv[i], hc * 128, 0, 0);
+            }
             if (++hc == nchunks) { hc = 0; hj++; }
         };
         WS_DIAG_DECL
         int pj = j0, pc = 0;                                 // step being produced: (pair, chunk)
         float4 wt[9];                                        // its depthwise taps
+        float4 sw[9], ssc, ssh;                              // STEM: the stem's taps and folded BN for the step's 32 channels (this lane's quad)
         const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc((void *)a.dw9, 0, 0x7fffffff, 0x00020000);
+        int cur_pc = 0;                                      // STEM: chunk of the step whose operands are being produced
         auto load_taps = [&]() {                             // buffer loads: per-lane offset fixed, (tap, chunk) in the scalar offset -- no vector arithmetic
+            if (!STEM) {
 #pragma unroll
-            for (int tp = 0; tp < 9; tp++)
-                wt[tp] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsT, q * 16, (tp * Cin + pc * 32) * 4, 0));
+                for (int tp = 0; tp < 9; tp++)
+                    wt[tp] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsT, q * 16, (tp * Cin + pc * 32) * 4, 0));
+            }
+            if (STEM) {
+                cur_pc = pc;
+                const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void *)a.stem_w, 0, 0x7fffffff, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void *)a.stem_scale, 0, 0x7fffffff, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void *)a.stem_shift, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+                for (int tp = 0; tp < 9; tp++)
+                    sw[tp] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsW, q * 16, (tp * Cin + pc * 32) * 4, 0));
+                ssc = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsC, q * 16, pc * 128, 0));
+                ssh = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsH, q * 16, pc * 128, 0));
+            }
         };
         // The f32 MFMA and the vector ALU do not run side by side on a SIMD: next to two consumer waves that keep the matrix
         // pipe full, a producer's FMAs issued once per 20-40 cycles whatever its priority (measured: 6 000-10 000 cycles for
@@ -222,12 +296,63 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
             WS_STAMP(0)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // taps, halo, weights: all landed before the phase ends
             WS_STAMP(1)
-            load_row(0, win[0]);
-            load_row(1, win[1]);
-            load_row(2, win[2]);
-            load_row(3, win[3]);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (!STEM) {            // (STEM: the halo does not exist yet -- it is computed at the top of the vector phase)
+                load_row(0, win[0]);
+                load_row(1, win[1]);
+                load_row(2, win[2]);
+                load_row(3, win[3]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             WS_STAMP(2)
+        };
+        // STEM: this producer's 10 x 10 halo of the step's 32 channels from the patch window.  Item i = halo pixel 8 i + (lane >> 3) (the pixel
+        // piece i of the plain form's LDS-DMA would carry), channel quad lane & 7: the 3 x 3 window pixels (stride 2: rows 2 hy .., columns
+        // 2 hx ..) as three 8-byte + three 4-byte broadcast reads, 36 multiply-adds in stem_kernel's order, folded BN, ReLU, one 16-byte write.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        auto stem_halo = [&]() {
+            // window reads one item ahead of the arithmetic, pinned: left alone, the scheduler hoists the reads of all 13 items to the top
+            // (117 live values: the kernel then spills, and scratch traffic shares vmcnt with the LDS-DMA).  The arithmetic is written on
+            // 2-vectors so that it compiles to v_pk_fma_f32 (18 per item for the taps, 2 for the folded BN); the zero padding outside the
+            // image is a multiplication by a 0 / 1 lane mask (exact: the values are finite and >= +0) instead of four selects.
+            float xw[2][9];
+            int xl_o = xl;                  // opaque: the 13 window addresses are recomputed per step instead of living in 13 registers
+            asm volatile("" : "+v"(xl_o));
+            auto read_item = [&](int i, float *x9) {
+                int hp = 8 * i + xl_o;
+                if (i == WS_NHP - 1) hp = hp < 100 ? hp : 99;        // pieces past the halo (zeroed below) must not read past the window
+                const int hy = (hp * 205) >> 11;                      // hp / 10 for hp < 1024
+                const int hx = hp - hy * 10;
+                const float *wb = Wp + (2 * hy) * WS_WPITCH + 2 * hx;
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++) {
+                    const float2 t2 = *reinterpret_cast<const float2 *>(wb + ky * WS_WPITCH);
+                    x9[ky * 3] = t2.x; x9[ky * 3 + 1] = t2.y; x9[ky * 3 + 2] = wb[ky * WS_WPITCH + 2];
+                }
+            };
+            const f32x2 sc01 = {ssc.x, ssc.y}, sc23 = {ssc.z, ssc.w}, sh01 = {ssh.x, ssh.y}, sh23 = {ssh.z, ssh.w};
+            read_item(0, xw[0]);
+#pragma unroll
+            for (int i = 0; i < WS_NHP; i++) {
+                if (i + 1 < WS_NHP) read_item(i + 1, xw[(i + 1) & 1]);
+                WS_PIN()
+                const float *x9 = xw[i & 1];
+                f32x2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll
+                for (int tp = 0; tp < 9; tp++) {
+                    const f32x2 vv = {x9[tp], x9[tp]};
+                    const f32x2 w01 = {sw[tp].x, sw[tp].y}, w23 = {sw[tp].z, sw[tp].w};
+                    a01 = __builtin_elementwise_fma(vv, w01, a01);
+                    a23 = __builtin_elementwise_fma(vv, w23, a23);
+                }
+                a01 = __builtin_elementwise_fma(a01, sc01, sh01);
+                a23 = __builtin_elementwise_fma(a23, sc23, sh23);
+                const float keep = ((badm >> i) & 1u) ? 0.f : 1.f;       // outside the image: the depthwise convolution's zero padding
+                const f32x2 kk = {keep, keep};
+                f32x2 o01 = {fmaxf(a01.x, 0.f), fmaxf(a01.y, 0.f)}, o23 = {fmaxf(a23.x, 0.f), fmaxf(a23.y, 0.f)};
+                o01 = o01 * kk; o23 = o23 * kk;
+                *reinterpret_cast<float4 *>(Hp + i * 256 + lane * 4) = make_float4(o01.x, o01.y, o23.x, o23.y);
+                WS_PIN()
+            }
         };
         // One round = two output rows (acc0: row y, acc1: row y + 1) from the window rows y .. y + 3, each chain in (ky, kx)
         // order.  (Tried and rejected, +3.6 ms over the four layers: requesting rows y + 4 / y + 5 in the middle of a round, as
@@ -243,6 +368,16 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
         };
         auto compute = [&](int stage) {
             float *As = smem + (stage ? WS_A1 : WS_A0);
+            if (STEM) {
+                stem_halo();
+                WS_PIN()
+#pragma unroll
+                for (int tp = 0; tp < 9; tp++) wt[tp] = *reinterpret_cast<const float4 *>(smem + WS_A + tp * Cin + cur_pc * 32 + q * 4);
+                load_row(0, win[0]);        // LDS operations of one wave execute in order: these reads see the writes above
+                load_row(1, win[1]);
+                load_row(2, win[2]);
+                load_row(3, win[3]);
+            }
 #pragma unroll
             for (int y = 0; y < 8; y += 2) {
                 if (y) {
@@ -705,8 +840,25 @@ bool launch_sepconv_ws(const float *in, int N, int H, int W, int Cin, int relu_i
         set_error("launch_sepconv_ws: unsupported shape");
         return false;
     }
-    WsArgs a{in, N, H, W, Cin, Cout, dw9, pwk, scale, shift, relu_out, out, nullptr, nullptr, nullptr, nullptr};
+    WsArgs a{in, N, H, W, Cin, Cout, dw9, pwk, scale, shift, relu_out, out, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     launch_ws_any<false>(a, relu_in, prec, s);
+    return true;
+}
+
+bool launch_sepconv_ws_stem(const float *x, int N, int H, int W, int Cin, const float *stem_w, const float *stem_scale, const float *stem_shift,
+                            const float *dw9, const float *pwk, int Cout, const float *scale, const float *shift, int relu_out, float *out,
+                            hipStream_t s)
+{
+    // the patch window offsets are 32-bit byte offsets from the tile's first window pixel: (21 rows of 2 W floats) always fits; the patch
+    // itself is addressed through a 64-bit base
+    if (!sepconv_ws_supported(H, W, Cin, Cout) || N <= 0 || (long long)N * (H / 16) * (W / 16) * (Cout / 128) > 0x3fffffffLL || 9 * Cin > WS_X) {
+        set_error("launch_sepconv_ws_stem: unsupported shape");
+        return false;
+    }
+    WsArgs a{x, N, H, W, Cin, Cout, dw9, pwk, scale, shift, relu_out, out, nullptr, nullptr, nullptr, nullptr, stem_w, stem_scale, stem_shift};
+    const int nMt = N * (H / 16) * (W / 16), nNt = Cout / 128;
+    const int G = (ws_cus() / 8) * 8;
+    hipLaunchKernelGGL((sepconv_ws_kernel<false, false, 0, true>), dim3(G), dim3(768), 0, s, a, nMt, nNt, G);
     return true;
 }
 
@@ -724,7 +876,7 @@ bool launch_sepconv_pool_ws(const float *in, int N, int H, int W, int Cin, int r
     }
     const size_t tiles = (size_t)N * (H / 16) * (W / 16);
     float *sh = scratch, *sv = sh + tiles * 8 * Cout, *co = sv + tiles * 8 * Cout;
-    WsArgs a{in, N, H, W, Cin, Cout, dw9, pwk, scale, shift, relu_out, out, resid, sh, sv, co};
+    WsArgs a{in, N, H, W, Cin, Cout, dw9, pwk, scale, shift, relu_out, out, resid, sh, sv, co, nullptr, nullptr, nullptr};
     launch_ws_any<true>(a, relu_in, prec, s);
     launch_pool_fix_add(out, sh, sv, co, resid, N, H, W, Cout, 8, s);
     return true;

@@ -327,7 +327,15 @@ int unet_down_dev(Ctx *c, const float *X, int n, float *dout, hipStream_t s)
     if (n > c->max_patches) { set_error("unet_down_dev: n > max_patches"); return TMAT_E_ARG; }
     const int P = c->patch;
     float *b0 = c->buf[0], *b1 = c->buf[1], *b2 = c->buf[2], *b3 = c->buf[3];
-    launch_stem(X, n, P, P, c->stem_w, c->f0, c->stem_scale, c->stem_shift, b0, s);
+    const int di = dout == c->dout[1] ? 1 : 0;
+    c->dout_relu_ok[di] = false;
+    // Block 0 on the wave-specialised separable kernel: the stem tensor is never materialised -- the first separable convolution's
+    // producers recompute it from the patch (sepconv_ws_kernel<..., STEM>), and the stride-2 residual convolution, which samples the
+    // even pixels only, reads those from stem_even_kernel's quarter-size tensor as a unit-stride 1x1 convolution.
+    const bool stem_in_sep = c->stem_fused && !c->down.empty() && down_block_ws(c, 0) && c->down[0].cin == c->f0 &&
+                             !(c->precision == TMAT_PRECISION_BF16X3 && c->sep_bf16);
+    if (stem_in_sep) launch_stem_even(X, n, P, P, c->stem_w, c->f0, c->stem_scale, c->stem_shift, b0, s);
+    else launch_stem(X, n, P, P, c->stem_w, c->f0, c->stem_scale, c->stem_shift, b0, s);
     int H = P / 2;
     for (size_t bi = 0; bi < c->down.size(); bi++) {
         auto &d = c->down[bi];
@@ -342,10 +350,14 @@ int unet_down_dev(Ctx *c, const float *X, int n, float *dout, hipStream_t s)
                 auto i0 = mp.find(d.pw[0]), i1 = mp.find(d.pw[1]);
                 if (i0 != mp.end() && i1 != mp.end()) { pw0 = i0->second; pw1 = i1->second; sprec = 1; }
             }
-            if (!launch_sepconv_ws(b0, n, H, H, d.cin, bi > 0, d.dw[0], pw0, d.cout, d.scale[0], d.shift[0], 1, b2, s, sprec)) return TMAT_E_ARG;
+            const bool stem_here = bi == 0 && stem_in_sep;
+            if (stem_here) {
+                if (!launch_sepconv_ws_stem(X, n, H, H, d.cin, c->stem_w, c->stem_scale, c->stem_shift, d.dw[0], pw0, d.cout, d.scale[0], d.shift[0], 1, b2, s)) return TMAT_E_ARG;
+            } else if (!launch_sepconv_ws(b0, n, H, H, d.cin, bi > 0, d.dw[0], pw0, d.cout, d.scale[0], d.shift[0], 1, b2, s, sprec)) return TMAT_E_ARG;
             ConvArgs r{};
             r.in = b0; r.N = n; r.h = H; r.w = H; r.Cin = d.cin; r.ksize = 1; r.stride = 2; r.W = d.res_w; r.Cout = d.cout;
             r.scale = nullptr; r.shift = d.res_b; r.out = b1;
+            if (stem_here) { r.h = H / 2; r.w = H / 2; r.stride = 1; }      // b0 holds the even pixels only
             if (!conv(c, r, s)) return TMAT_E_ARG;
             float *nxt = bi + 1 == c->down.size() ? dout : b0;
             if (c->fused_pool) {
@@ -389,7 +401,10 @@ int unet_down_dev(Ctx *c, const float *X, int n, float *dout, hipStream_t s)
         r.in = b0; r.N = n; r.h = H; r.w = H; r.Cin = d.cin; r.ksize = 1; r.stride = 2; r.W = d.res_w; r.Cout = d.cout;
         r.scale = nullptr; r.shift = d.res_b; r.out = b1;
         if (!conv(c, r, s)) return TMAT_E_ARG;
-        launch_maxpool_add(b2, n, H, H, d.cout, b1, bi + 1 == c->down.size() ? dout : b0, s);
+        const bool last = bi + 1 == c->down.size();
+        float *dr = (last && c->relu_copy && dout == c->dout[di]) ? c->dout_relu[di] : nullptr;      // activated copy for the first up block
+        launch_maxpool_add(b2, n, H, H, d.cout, b1, last ? dout : b0, s, dr);
+        if (dr) c->dout_relu_ok[di] = true;
         H /= 2;
     }
     TMAT_HIP(hipGetLastError());
@@ -405,10 +420,14 @@ int unet_up_dev(Ctx *c, const float *dout, int n, float *Y, hipStream_t s)
     int Hs = c->patch >> (1 + c->down.size()), up = 0;
     float *t1 = c->ubuf[0], *rr = c->ubuf[1];
     int so_idx = 2;
-    for (auto &u : c->up) {
+    // S_act: the activated copy of S when its producer wrote one (the block's first convolution then needs no ReLU on load)
+    const int di = dout == c->dout[1] ? 1 : 0;
+    const float *S_act = (c->relu_copy && dout == c->dout[di] && c->dout_relu_ok[di]) ? c->dout_relu[di] : nullptr;
+    for (size_t j = 0; j < c->up.size(); j++) {
+        auto &u = c->up[j];
         float *so = c->ubuf[so_idx];
         ConvArgs a{};
-        a.in = S; a.N = n; a.h = Hs; a.w = Hs; a.Cin = u.cin; a.relu_in = 1; a.ksize = 3; a.stride = 1;
+        a.in = S_act ? S_act : S; a.N = n; a.h = Hs; a.w = Hs; a.Cin = u.cin; a.relu_in = S_act ? 0 : 1; a.ksize = 3; a.stride = 1;
         a.W = u.ct[0];
         if (up) { a.ksize = 2; a.W = u.ct_sub; }      // 4 taps per output parity class instead of 9
         a.Cout = u.cout; a.scale = u.scale[0]; a.shift = u.shift[0]; a.relu_out = 1; a.out = t1;
@@ -422,8 +441,11 @@ int unet_up_dev(Ctx *c, const float *dout, int n, float *Y, hipStream_t s)
         b.in = t1; b.N = n; b.h = Hl; b.w = Hl; b.Cin = u.cout; b.relu_in = 0; b.ksize = 3; b.stride = 1;
         b.W = u.ct[1]; b.Cout = u.cout; b.scale = u.scale[1]; b.shift = u.shift[1]; b.resid = rr; b.rs = up; b.relu_out = 0;
         b.out = so;
+        // the next block's first convolution reads relu(so): written here as a second output (the last block's output feeds the final conv as is)
+        float *so_act = (c->relu_copy && j + 1 < c->up.size()) ? c->urelu[j & 1] : nullptr;
+        b.out_relu = so_act;
         if (!conv(c, b, s)) return TMAT_E_ARG;
-        S = so; so_idx = so_idx == 2 ? 3 : 2;
+        S = so; S_act = so_act; so_idx = so_idx == 2 ? 3 : 2;
         Hs = Hl; up = 1;
     }
     launch_final(S, n, Hs, Hs, c->f_last, c->final_w, c->final_b, Y, s);
@@ -543,6 +565,7 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
     if (const char *e = getenv("TMAT_FUSED_SEP")) c->fused_sep = atoi(e) != 0;
     if (const char *e = getenv("TMAT_FUSED_POOL")) c->fused_pool = atoi(e) != 0;
     if (const char *e = getenv("TMAT_SEP_WS")) c->sep_ws = atoi(e) != 0;
+    if (const char *e = getenv("TMAT_STEM_FUSED")) c->stem_fused = atoi(e) != 0;
     if (const char *e = getenv("TMAT_SEP_BF16")) c->sep_bf16 = atoi(e) != 0;
     const char *prec_env = getenv("TMAT_PRECISION");
     if (prec_env && strcmp(prec_env, "f32") && strcmp(prec_env, "bf16x3") && strcmp(prec_env, "bf16x6")) {
@@ -581,6 +604,20 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
         if (!hip_ok(hipMalloc((void **)&c->dout[i], c->dout_bytes), "hipMalloc(dout)")) {
             tmat_destroy((tmat_handle)c); return TMAT_E_HIP;
         }
+    if (const char *e = getenv("TMAT_RELU_COPY")) c->relu_copy = atoi(e) != 0;
+    if (c->relu_copy) {
+        // up block j's output has (P/16 << j)^2 x cout_j values per patch: the larger of the even / odd blocks sizes each buffer
+        size_t need[2] = {0, 0};
+        for (size_t j = 0; j + 1 < c->up.size(); j++) {
+            const size_t side = (size_t)(patch >> (1 + c->down.size())) << j;
+            need[j & 1] = std::max(need[j & 1], side * side * c->up[j].cout);
+        }
+        for (int i = 0; i < 2; i++) {
+            c->urelu_bytes[i] = need[i] * c->max_patches * sizeof(float);
+            if (!hip_ok(hipMalloc((void **)&c->dout_relu[i], c->dout_bytes), "hipMalloc(dout_relu)") ||
+                (need[i] && !hip_ok(hipMalloc((void **)&c->urelu[i], c->urelu_bytes[i]), "hipMalloc(urelu)"))) { tmat_destroy((tmat_handle)c); return TMAT_E_HIP; }
+        }
+    }
     if (!hip_ok(hipStreamCreate(&c->stream2), "hipStreamCreate(2)") || !hip_ok(hipStreamCreateWithPriority(&c->stream3, hipStreamDefault, prio_least), "hipStreamCreate(3)")) {
         tmat_destroy((tmat_handle)c); return TMAT_E_HIP;
     }
@@ -638,6 +675,7 @@ void tmat_destroy(tmat_handle h)
     if (c->stream2) hipStreamSynchronize(c->stream2);
     for (int i = 0; i < 4; i++) if (c->buf[i]) hipFree(c->buf[i]);
     for (int i = 0; i < 4; i++) if (c->ubuf[i]) hipFree(c->ubuf[i]);
+    for (int i = 0; i < 2; i++) { if (c->dout_relu[i]) hipFree(c->dout_relu[i]); if (c->urelu[i]) hipFree(c->urelu[i]); }
     for (int i = 0; i < 2; i++) { if (c->dout[i]) hipFree(c->dout[i]); if (c->ev_down[i]) hipEventDestroy(c->ev_down[i]); if (c->ev_up[i]) hipEventDestroy(c->ev_up[i]); if (c->ev_blend[i]) hipEventDestroy(c->ev_blend[i]); }
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->stream3) { hipStreamSynchronize(c->stream3); hipStreamDestroy(c->stream3); }
@@ -788,6 +826,7 @@ int tmat_debug_poison(tmat_handle h, int byte_pattern)
     std::vector<WsEnt> all;
     for (int i = 0; i < 4; i++) { if (c->buf[i]) all.push_back({c->buf[i], c->buf_bytes[i], false}); if (c->ubuf[i]) all.push_back({c->ubuf[i], c->ubuf_bytes[i], false}); }
     for (int i = 0; i < 2; i++) if (c->dout[i]) all.push_back({c->dout[i], c->dout_bytes, false});
+    for (int i = 0; i < 2; i++) { if (c->dout_relu[i]) all.push_back({c->dout_relu[i], c->dout_bytes, false}); if (c->urelu[i]) all.push_back({c->urelu[i], c->urelu_bytes[i], false}); }
     const size_t pio = (size_t)c->patch * c->patch * c->patch_cap * sizeof(float);
     if (c->patch_in) all.push_back({c->patch_in, pio, false});
     if (c->patch_out) all.push_back({c->patch_out, pio, false});

@@ -107,6 +107,13 @@ struct Ctx {
     float *buf[4] = {nullptr, nullptr, nullptr, nullptr};    // down-path ping-pong activations
     float *ubuf[4] = {nullptr, nullptr, nullptr, nullptr};   // up-path activations
     float *dout[2] = {nullptr, nullptr};                     // down-path output (P/16)^2 x f_deep, double-buffered
+    // activated copies (max(x, +0)) of the tensors a block's first convolution reads: the bottleneck (written by the last pooling) and
+    // the outputs of up blocks 0 .. n-2 (written by conv_mfma_kernel's epilogue); TMAT_RELU_COPY=0: ReLU on load instead
+    bool relu_copy = true;
+    float *dout_relu[2] = {nullptr, nullptr};
+    bool dout_relu_ok[2] = {false, false};                   // the last down-path call wrote dout_relu[i] (only the unfused last block does)
+    float *urelu[2] = {nullptr, nullptr};
+    size_t urelu_bytes[2] = {0, 0};
     hipStream_t stream2 = nullptr;                           // second stream: down path of pass p+1 overlaps up path of pass p
     hipStream_t stream3 = nullptr;                           // third stream: finish stage of pass p-1 (after the host thinning)
     hipEvent_t ev_down[2] = {nullptr, nullptr};
@@ -154,6 +161,7 @@ struct Ctx {
     std::map<int, std::map<const float *, float *>> wsplit;  // precision mode -> (... -> its split-precision copy on the device, made on first use)
     bool sep_ws = true;                                      // wave-specialised form of the fused separable kernel (TMAT_SEP_WS=0: sepconv_mfma_kernel)
     bool sep_bf16 = true;                                    // bf16x3 mode also runs the separable layers' pointwise part on the bf16 cores (TMAT_SEP_BF16=0: f32)
+    bool stem_fused = true;                                  // the stem recomputed inside block 0's first separable convolution (TMAT_STEM_FUSED=0: stem_kernel writes its tensor)
     bool fused_sep = true;                                   // fused depthwise->pointwise kernel where the level allows (TMAT_FUSED_SEP=0: off)
     // profiling of the dominant kernel family
     bool prof_on = false;

@@ -26,6 +26,7 @@ struct ConvArgs {
     int rs;
     int relu_out;
     float *out;           // (N, h/stride, w/stride, Cout); ksize 2: (N, 2h, 2w, Cout)
+    float *out_relu;      // nullable (ksize 1 / 3 only): a second, activated copy max(v, +0) of the output -- for a consumer that would otherwise apply ReLU on load
     int prec;             // 0: f32 MFMA (bit-exact contract); 1: bf16x3 split precision, W then points to the split copy of the weights
 };
 // returns false (and sets the error) on unsupported shapes
@@ -47,7 +48,16 @@ bool launch_sepconv_pool_ws(const float *in, int N, int H, int W, int Cin, int r
 void launch_dwconv(const float *in, int N, int H, int W, int C, int relu_in, const float *Wd, float *out, hipStream_t s);
 void launch_stem(const float *x, int N, int H, int W, const float *Ws, int Cout, const float *scale,
                  const float *shift, float *out, hipStream_t s);
-void launch_maxpool_add(const float *p2, int N, int H, int W, int C, const float *r, float *out, hipStream_t s);
+// the stem at the even output pixels only: out (N, H/4, W/4, Cout); the input of block 0's stride-2 residual convolution when the stem
+// itself is recomputed inside the first separable convolution (launch_sepconv_ws_stem)
+void launch_stem_even(const float *x, int N, int H, int W, const float *Ws, int Cout, const float *scale,
+                      const float *shift, float *out, hipStream_t s);
+// SeparableConv2D over the stem's output WITHOUT the stem tensor in memory: x (N, 2H, 2W) single-channel patches; the depthwise
+// producers recompute stem = relu(bn(conv3x3/s2(x))) (H x W x Cin) for their halo.  Same results as launch_stem + launch_sepconv_ws.
+bool launch_sepconv_ws_stem(const float *x, int N, int H, int W, int Cin, const float *stem_w, const float *stem_scale, const float *stem_shift,
+                            const float *dw9, const float *pwk, int Cout, const float *scale, const float *shift, int relu_out, float *out,
+                            hipStream_t s);
+void launch_maxpool_add(const float *p2, int N, int H, int W, int C, const float *r, float *out, hipStream_t s, float *out_relu = nullptr);
 void launch_final(const float *S, int N, int h, int w, int C, const float *Wf, float bias, float *out, hipStream_t s);
 
 // ---- tiling / blending (blend_kernels.hip) -------------------------------------------------

@@ -60,6 +60,10 @@ static FastDiv make_fastdiv(int d)
 }
 __device__ __forceinline__ int fdiv(int n, FastDiv f) { return (int)(__umulhi((unsigned)n, f.mul) >> f.sh); }
 
+// ReLU as one v_max_i32: as a signed integer a negative float (and -0.0) is negative, so max with 0 gives x > 0 ? x : +0.0 exactly
+// (no NaNs on this path), without fmaxf's choice between the two zeros
+__device__ __forceinline__ float relu_pos0(float v) { return __builtin_bit_cast(float, max(__builtin_bit_cast(int, v), 0)); }
+
 // PREC = 0: f32 operands on v_mfma_f32_32x32x2_f32 (the bit-exact path, everything above).
 // PREC = 1, 2: split precision on the bf16 matrix cores, opt-in (tmat_set_precision), f32 accumulation:
 //   1 "bf16x3": x = hi + lo (hi = rne_bf16(x), lo = rne_bf16(x - hi)); a w ~ a_lo w_hi + a_hi w_lo + a_hi w_hi: three
@@ -80,7 +84,13 @@ template <int BM, int BN, int WM, int WN, int KS, bool RELU, int PREC = 0>
 #ifndef TMAT_CONV_WPS
 #define TMAT_CONV_WPS 4     // waves per SIMD the 8-wave conv kernel is compiled for (VGPR budget 512 / this)
 #endif
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 > 65536 ? 2 : WM * WN == 8 ? TMAT_CONV_WPS : 2)) void conv_mfma_kernel(ConvArgs a, int M, int Ho, int Wo, int nMt, int nNt, FastDiv dHW, FastDiv dW, int nstat)
+#ifndef TMAT_CONV64_WPS
+#define TMAT_CONV64_WPS TMAT_CONV_WPS     // the same for the 8-wave 128 x 64 tile of the Cout = 64 layers (3 workgroups per CU need 6)
+#endif
+#ifndef TMAT_CONV4_WPS
+#define TMAT_CONV4_WPS 2    // 4-wave workgroups
+#endif
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 > 65536 ? 2 : WM * WN == 8 ? (BM == 128 && BN == 64 ? TMAT_CONV64_WPS : TMAT_CONV_WPS) : TMAT_CONV4_WPS)) void conv_mfma_kernel(ConvArgs a, int M, int Ho, int Wo, int nMt, int nNt, FastDiv dHW, FastDiv dW, int nstat)
 {
     // KS (1, 2 or 3) is a template parameter so that the 3x3 and the pointwise instantiations are distinct kernels
     // (distinct names in rocprofv3 traces: the 3x3 <128,128,2,2,3,*> instantiations are the dominant kernel).
@@ -502,6 +512,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
         const float relu_lo = a.relu_out ? 0.f : -__builtin_inff();
         const size_t tbase = (size_t)mw * a.Cout + n0 + wn * (BN / WN);
         char *const obase = reinterpret_cast<char *>(a.out + tbase);
+        char *const o2base = reinterpret_cast<char *>(a.out_relu + tbase);                // used when a.out_relu only
         const char *const rbase = reinterpret_cast<const char *>(a.resid + tbase);       // used for rs == 0 only
 #pragma unroll 4
         for (int it = 0; it < WROWS / RPW; it++) {
@@ -535,7 +546,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
                     *reinterpret_cast<float4 *>(a.out + oidx * a.Cout + co) = v;
                 }
             }
-            else if (ok) *reinterpret_cast<float4 *>(obase + so + vo) = v;
+            else if (ok) {
+                *reinterpret_cast<float4 *>(obase + so + vo) = v;
+                // the activated copy for the next block's first convolution (uniform branch): four v_max per 16-byte store here instead of
+                // sixteen v_max_i32 per K chunk and wave in the consumer's RELU instantiation (0.7 ms per launch)
+                if (a.out_relu) {       // relu_pos0: negative values and -0.0 become +0.0, exactly what the RELU instantiation's load-side max does
+                    v.x = relu_pos0(v.x); v.y = relu_pos0(v.y); v.z = relu_pos0(v.z); v.w = relu_pos0(v.w);
+                    *reinterpret_cast<float4 *>(o2base + so + vo) = v;
+                }
+            }
         }
     }
 #ifdef TMAT_DIAG
@@ -604,6 +623,11 @@ static void launch_conv_cfg(const ConvArgs &a, int M, int Ho, int Wo, hipStream_
 #define TMAT_64_WM 4
 #define TMAT_64_WN 2
 #endif
+#ifndef TMAT_64S_BM
+#define TMAT_64S_BM 256 // tile of the sub-pixel Cout = 64 layer
+#define TMAT_64S_WM 8
+#define TMAT_64S_WN 1
+#endif
 
 bool launch_conv(const ConvArgs &a, hipStream_t s)
 {
@@ -612,7 +636,7 @@ bool launch_conv(const ConvArgs &a, hipStream_t s)
     if (!((a.ksize == 3 && a.stride == 1) || (a.ksize == 2 && a.stride == 1 && !a.resid) ||
           (a.ksize == 1 && (a.stride == 1 || a.stride == 2))) || a.Cin % 32 || a.Cout % 64 ||
         ((a.ksize * a.ksize * (a.Cin / 32)) & 1) || Mll <= 0 ||
-        Mll > 0x7fffffffLL / 2 || (a.resid && a.rs && ((Ho | Wo) & 1)) || Wo < 2) {
+        Mll > 0x7fffffffLL / 2 || (a.resid && a.rs && ((Ho | Wo) & 1)) || Wo < 2 || (a.out_relu && a.ksize == 2)) {
         set_error("launch_conv: unsupported shape");
         return false;
     }
@@ -622,7 +646,7 @@ bool launch_conv(const ConvArgs &a, hipStream_t s)
     else if (a.ksize == 2)
         // the sub-pixel layer with 64 output channels (16 chunks per tile, four parity classes): 256 x 64 tiles of eight 32 x 64 wave blocks
         // -- 32 MFMAs per wave and chunk instead of 16 -- measure 20.6 against 21.5 ms; the 3 x 3 layer prefers 128 x 64 (22.7 against 23.2)
-        launch_conv_ks<256, 64, 8, 1, 2>(a, M, Ho, Wo, s);
+        launch_conv_ks<TMAT_64S_BM, 64, TMAT_64S_WM, TMAT_64S_WN, 2>(a, M, Ho, Wo, s);
     else if (a.ksize == 3 && a.prec != 0)          // split precision: a chunk is short, the A-tile traffic per MFMA decides (12.5 -> 11.4 ms in bf16x3)
         launch_conv_ks<256, 64, 8, 1, 3>(a, M, Ho, Wo, s);
     else
@@ -638,16 +662,20 @@ constexpr int DW_ROWS = 8;      // output rows per thread (a 3-row window slides
 #ifndef TMAT_DW_WPS
 #define TMAT_DW_WPS 1
 #endif
-__global__ __launch_bounds__(256, TMAT_DW_WPS) void dwconv_kernel(const float *__restrict__ in, int H, int W, int C, int c4shift,
-                                                     int relu_in, const float *__restrict__ Wd, float *__restrict__ out)
+__global__ __launch_bounds__(256, TMAT_DW_WPS) void dwconv_kernel(const float *__restrict__ in, int N, int H, int W, int C, int c4shift,
+                                                     int relu_in, const float *__restrict__ Wd, float *__restrict__ out, int bpp)
 {
     // grid: (ceil((H/8) * (W/4) * C4 / 256), N).  One thread = a strip of 4 consecutive pixels x 8 rows x 4 channels.
     // The 3 x 6 input window slides down the strip: every new output row costs 6 float4 loads for 4 float4 stores
     // (1.9 loads per store over the strip instead of 4.5 for an isolated 3 x 6 window).  Lanes that are adjacent in the
     // channel-group index read adjacent 16 B, so every load instruction moves whole 128-byte lines.
     // 32-bit index math; C4 = C/4 is a power of two.
-    const int n = blockIdx.y;
-    const int e = blockIdx.x * 256 + threadIdx.x;
+    // 1-D grid, XCD-aware (round 4): block b runs on XCD b & 7; the bpp blocks of one patch go to one XCD, consecutively, so the rows
+    // two vertically adjacent strips share (10 input rows per 8 output rows) are fetched by one L2 only
+    const int bj = blockIdx.x >> 3;
+    const int n = (bj / bpp) * 8 + (blockIdx.x & 7);
+    if (n >= N) return;
+    const int e = (bj % bpp) * 256 + threadIdx.x;
     const int C4 = 1 << c4shift;
     const int cq = e & (C4 - 1);
     const int g = e >> c4shift;                 // strip index
@@ -701,7 +729,8 @@ void launch_dwconv(const float *in, int N, int H, int W, int C, int relu_in, con
 {
     const int C4 = C / 4;
     const int total = (H / DW_ROWS) * (W / 4) * C4;     // H % 8 == 0 and W % 4 == 0 for every level of the model (checked in tmat_create)
-    hipLaunchKernelGGL(dwconv_kernel, dim3((total + 255) / 256, N), dim3(256), 0, s, in, H, W, C, ilog2(C4), relu_in, Wd, out);
+    const int bpp = (total + 255) / 256;
+    hipLaunchKernelGGL(dwconv_kernel, dim3((unsigned)(((N + 7) / 8) * 8 * bpp)), dim3(256), 0, s, in, N, H, W, C, ilog2(C4), relu_in, Wd, out, bpp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -754,6 +783,60 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ x, 
     }
 }
 
+// The stem at the EVEN output pixels only: out (N, H/4, W/4, Cout), out[yo][xo] = stem(x)[2 yo][2 xo].  When the stem itself is
+// recomputed inside the first separable convolution's depthwise producers (sepconv_ws_kernel<..., STEM>), the only other reader of the
+// stem tensor is block 0's 1x1 / stride-2 residual convolution (models.py:140), which samples exactly these pixels: a quarter of the
+// tensor (2.6 instead of 10.5 GB per pass of 1600 patches) and a unit-stride 1x1 convolution behind it.  Same chain as stem_kernel.
+__global__ __launch_bounds__(256) void stem_even_kernel(const float *__restrict__ x, int H, int W, const float *__restrict__ Ws,
+                                                        int Cout, int c4shift, const float *__restrict__ scale,
+                                                        const float *__restrict__ shift, float *__restrict__ out)
+{
+    // One thread = 4 consecutive output pixels of a row x 4 channels: the 3 rows x 16 input columns they touch (columns 16 g .. 16 g + 14)
+    // as 12 aligned 16-byte loads shared by the 16 channel-quad lanes of a pixel group, the taps and the folded BN once per thread.
+    const int Ho = H >> 2, Wo = W >> 2, WG = Wo >> 2;           // (W / 4) % 4 == 0: the patch size is a multiple of 64
+    const int n = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    const int cq = e & ((1 << c4shift) - 1);
+    const int g = e >> c4shift;
+    if (g >= Ho * WG) return;
+    const int yo = g / WG, xg = g - yo * WG;
+    const float *xin = x + (size_t)n * H * W + (size_t)(4 * yo) * W + 16 * xg;      // rows 4 yo .. 4 yo + 2 < H, columns 16 xg .. 16 xg + 15 < W
+    float win[3][16];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c4 = 0; c4 < 4; c4++) {
+            const float4 v = *reinterpret_cast<const float4 *>(xin + r * W + c4 * 4);
+            win[r][c4 * 4] = v.x; win[r][c4 * 4 + 1] = v.y; win[r][c4 * 4 + 2] = v.z; win[r][c4 * 4 + 3] = v.w;
+        }
+    float4 wt[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; tp++) wt[tp] = *reinterpret_cast<const float4 *>(Ws + tp * Cout + cq * 4);
+    const float4 sc = *reinterpret_cast<const float4 *>(scale + cq * 4);
+    const float4 sh = *reinterpret_cast<const float4 *>(shift + cq * 4);
+    float *obase = out + ((size_t)n * Ho * Wo + (size_t)yo * Wo + 4 * xg) * Cout + cq * 4;
+#pragma unroll
+    for (int px = 0; px < 4; px++) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int tp = 0; tp < 9; tp++) {
+            const float v = win[tp / 3][4 * px + tp % 3];
+            acc.x = fmaf(v, wt[tp].x, acc.x); acc.y = fmaf(v, wt[tp].y, acc.y); acc.z = fmaf(v, wt[tp].z, acc.z); acc.w = fmaf(v, wt[tp].w, acc.w);
+        }
+        float4 o;
+        o.x = fmaxf(fmaf(acc.x, sc.x, sh.x), 0.f); o.y = fmaxf(fmaf(acc.y, sc.y, sh.y), 0.f);
+        o.z = fmaxf(fmaf(acc.z, sc.z, sh.z), 0.f); o.w = fmaxf(fmaf(acc.w, sc.w, sh.w), 0.f);
+        *reinterpret_cast<float4 *>(obase + (size_t)px * Cout) = o;
+    }
+}
+
+void launch_stem_even(const float *x, int N, int H, int W, const float *Ws, int Cout, const float *scale,
+                      const float *shift, float *out, hipStream_t s)
+{
+    const int total = (H / 4) * (W / 16) * (Cout / 4);
+    hipLaunchKernelGGL(stem_even_kernel, dim3((total + 255) / 256, N), dim3(256), 0, s, x, H, W, Ws, Cout, ilog2(Cout / 4), scale, shift, out);
+}
+
 void launch_stem(const float *x, int N, int H, int W, const float *Ws, int Cout, const float *scale,
                  const float *shift, float *out, hipStream_t s)
 {
@@ -765,7 +848,7 @@ void launch_stem(const float *x, int N, int H, int W, const float *Ws, int Cout,
 // MaxPooling2D(3, strides=2, "same") + residual add (models.py:138-144)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool_add_kernel(const float *__restrict__ p2, int H, int W, int C, int c4shift,
-                                                          const float *__restrict__ r, float *__restrict__ out)
+                                                          const float *__restrict__ r, float *__restrict__ out, float *__restrict__ out_relu)
 {
     const int Ho = H >> 1, Wo = W >> 1;
     const int n = blockIdx.y;
@@ -789,12 +872,16 @@ __global__ __launch_bounds__(256) void maxpool_add_kernel(const float *__restric
     const float4 rv = *reinterpret_cast<const float4 *>(r + o);
     m.x = m.x + rv.x; m.y = m.y + rv.y; m.z = m.z + rv.z; m.w = m.w + rv.w;
     *reinterpret_cast<float4 *>(out + o) = m;
+    if (out_relu) {         // activated copy for the first up block's convolution (see conv_mfma_kernel's epilogue)
+        m.x = relu_pos0(m.x); m.y = relu_pos0(m.y); m.z = relu_pos0(m.z); m.w = relu_pos0(m.w);
+        *reinterpret_cast<float4 *>(out_relu + o) = m;
+    }
 }
 
-void launch_maxpool_add(const float *p2, int N, int H, int W, int C, const float *r, float *out, hipStream_t s)
+void launch_maxpool_add(const float *p2, int N, int H, int W, int C, const float *r, float *out, hipStream_t s, float *out_relu)
 {
     const int total = (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(maxpool_add_kernel, dim3((total + 255) / 256, N), dim3(256), 0, s, p2, H, W, C, ilog2(C / 4), r, out);
+    hipLaunchKernelGGL(maxpool_add_kernel, dim3((total + 255) / 256, N), dim3(256), 0, s, p2, H, W, C, ilog2(C / 4), r, out, out_relu);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -824,24 +911,43 @@ __device__ __forceinline__ float exp_det(float x)
 // 4-channel group and feeds the 16 (class, slot) products.  Chain order per output (shared with oracle orc_final):
 // 4-channel group ascending, inside a group slot-major (a, b), then channel ascending.  Weights Wq laid out
 // [C/4][4 classes][4 slots][4] are wave-uniform: hipcc reads them with scalar loads, so LDS only carries the pixels.
-// One block = 8 x 16 stored pixels (16 x 32 outputs); the 10 x 18 stored pixels they touch are staged in LDS with the
-// pixel stride padded to C + 4 floats (conflict-free 16-byte reads of neighbouring pixels).
-__global__ __launch_bounds__(128) void final_kernel(const float *__restrict__ S, int h, int w, int C, int CB,
+// One block = 8 x 16 stored pixels (16 x 32 outputs); the 10 x 18 stored pixels they touch are staged in LDS.
+//
+// LDS layout (round 4): pixel stride CP = CB + 4 floats (36 for CB = 32: the 16 pixels of a tile row then name 16 distinct 16-byte
+// bank groups) and a ROW pitch that is a multiple of 64 floats.  A ds_read_b128 is served in the 16-lane groups {0-3, 12-15, 20-27},
+// {4-11, 16-19, 28-31}: with 16 threads per tile row a group takes columns {0-3, 12-15} from one tile row and {4-11} from the next,
+// so the rows must start at the same bank -- with the natural pitch 18 CP = 648 floats (8 banks further) two of every 16 reads
+// collided (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.595, profiles/r03_pmc_layers.txt).
+// CB is a template parameter (round 4): with a runtime CB the tile fill divided by CB / 4 and by 18 at run time (~35 vector
+// instructions per division, 4 divisions per element) -- 1.3 of the kernel's 2.0 G vector instructions were index arithmetic, and the
+// kernel sat at its vector-issue time (3.7 ms) instead of its 11.1 GB of reads.
+//
+// Block -> tile mapping (round 4): 1-D grid; block b runs on XCD b & 7 (round-robin dispatch), and all tiles of one patch go to ONE
+// XCD (patch = 8 (j / tpp) + xcd, tile = j % tpp, j = b >> 3), consecutively: the 10 x 18 halos of neighbouring tiles overlap by
+// 41 %, and with the (x, y, patch) grid of rounds 1-3 neighbours sat on different XCDs, so every XCD's L2 fetched the overlap again
+// (15.6 GB of fabric reads for an 11.1 GB tensor).
+template <int CB>
+__global__ __launch_bounds__(128) void final_kernel(const float *__restrict__ S, int N, int h, int w, int C, int tw, int tpp,
                                                     const float *__restrict__ Wq, float bias, float *__restrict__ out)
 {
     // The channels go through LDS in blocks of CB (the chain order -- 4-channel groups ascending -- is unchanged, the four
-    // accumulators live in registers across the blocks): with CB = 32 a workgroup holds 25 KiB instead of 49, six of them
+    // accumulators live in registers across the blocks): with CB = 32 a workgroup holds 28 KiB instead of 49, five of them
     // fit a CU instead of three, and the fill of one overlaps the arithmetic of the others.
-    extern __shared__ __attribute__((aligned(16))) float tile[];    // [10][18][CB + 4]
-    const int CP = CB + 4;
-    const int n = blockIdx.z;
-    const int j0 = blockIdx.x * 16, i0 = blockIdx.y * 8;
-    const int B4 = CB >> 2;
+    constexpr int CP = CB + 4, B4 = CB / 4;
+    constexpr int RPITCH = ((18 * CP + 63) / 64) * 64;
+    static_assert((B4 & (B4 - 1)) == 0, "channel quads per block: a power of two");
+    __shared__ __attribute__((aligned(16))) float tile[10 * RPITCH];    // [10][18 (+ pad)][CB + 4]
+    const int bj = blockIdx.x >> 3;
+    const int n = (bj / tpp) * 8 + (blockIdx.x & 7);
+    if (n >= N) return;
+    const int tile_id = bj % tpp;
+    const int j0 = (tile_id % tw) * 16, i0 = (tile_id / tw) * 8;
     const int qy = threadIdx.x >> 4, qx = threadIdx.x & 15;
     const int i = i0 + qy, jj = j0 + qx;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};             // classes (py, px) = (0,0), (0,1), (1,0), (1,1)
-    const float *t0 = tile + (qy * 18 + qx) * CP;    // stored pixel (i - 1, j - 1)
-    const int total = 10 * 18 * B4;
+    const float *t0 = tile + qy * RPITCH + qx * CP;  // stored pixel (i - 1, j - 1)
+    constexpr int total = 10 * 18 * B4;
+    const float *Sn = S + (size_t)n * h * w * C;
     for (int cb = 0; cb < C; cb += CB) {
         if (cb) __syncthreads();                     // the previous block of channels has been consumed
         // tile fill in batches of 8 loads per thread (all in flight together), then 8 LDS stores
@@ -850,26 +956,30 @@ __global__ __launch_bounds__(128) void final_kernel(const float *__restrict__ S,
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int e = e0 + u * 128;
-                const int cq = e % B4, p = e / B4;
-                const int ly = i0 - 1 + p / 18, lx = j0 - 1 + p % 18;
+                const int cq = e & (B4 - 1), p = e / B4;
+                const int py = p / 18, px = p - py * 18;
+                const int ly = i0 - 1 + py, lx = j0 - 1 + px;
                 const bool ok = e < total && ly >= 0 && ly < h && lx >= 0 && lx < w;
-                v[u] = *reinterpret_cast<const float4 *>(S + (ok ? (((size_t)n * h + ly) * w + lx) * C + cb + cq * 4 : (size_t)0));
+                v[u] = *reinterpret_cast<const float4 *>(Sn + (ok ? ((size_t)ly * w + lx) * C + cb + cq * 4 : (size_t)0));
                 if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int e = e0 + u * 128;
-                if (e < total) *reinterpret_cast<float4 *>(tile + (e / B4) * CP + (e % B4) * 4) = v[u];
+                const int cq = e & (B4 - 1), p = e / B4;
+                const int py = p / 18, px = p - py * 18;
+                if (e < total) *reinterpret_cast<float4 *>(tile + py * RPITCH + px * CP + cq * 4) = v[u];
             }
         }
         __syncthreads();
         if (i < h && jj < w) {
+#pragma unroll 2
             for (int cg = 0; cg < B4; cg++) {
                 float4 v[3][3];
 #pragma unroll
                 for (int r = 0; r < 3; r++)
 #pragma unroll
-                    for (int c = 0; c < 3; c++) v[r][c] = *reinterpret_cast<const float4 *>(t0 + (r * 18 + c) * CP + cg * 4);
+                    for (int c = 0; c < 3; c++) v[r][c] = *reinterpret_cast<const float4 *>(t0 + r * RPITCH + c * CP + cg * 4);
                 const float *wq = Wq + ((cb >> 2) + cg) * 64;
 #pragma unroll
                 for (int cls = 0; cls < 4; cls++)
@@ -896,11 +1006,16 @@ __global__ __launch_bounds__(128) void final_kernel(const float *__restrict__ S,
 // Wq: [C/4][4][4][4] (tmat_api.cpp:final_subpixel_weights)
 void launch_final(const float *S, int N, int h, int w, int C, const float *Wq, float bias, float *out, hipStream_t s)
 {
-    dim3 grid((w + 15) / 16, (h + 7) / 8, N);
-    static const int cb_env = [] { const char *e = getenv("TMAT_FINAL_CB"); return e ? atoi(e) : 32; }();
-    const int CB = (cb_env > 0 && cb_env % 4 == 0 && C % cb_env == 0) ? cb_env : C;      // channels per LDS block
-    const size_t lds = (size_t)(10 * 18 * (CB + 4)) * sizeof(float);
-    hipLaunchKernelGGL(final_kernel, grid, dim3(128), lds, s, S, h, w, C, CB, Wq, bias, out);
+    const int tw = (w + 15) / 16, tpp = tw * ((h + 7) / 8);
+    const dim3 grid((unsigned)(((N + 7) / 8) * 8 * tpp));           // N <= max_patches and tpp = 200 at 160 x 160: far below 2^31
+    // channels per LDS block: 32 when the channel count allows (every shipped model: C = 64), else 16 / 8 / 4 (C % 4 == 0: tmat_create)
+#ifndef TMAT_FINAL_CB
+#define TMAT_FINAL_CB 32
+#endif
+    if (C % 32 == 0) hipLaunchKernelGGL(final_kernel<TMAT_FINAL_CB>, grid, dim3(128), 0, s, S, N, h, w, C, tw, tpp, Wq, bias, out);
+    else if (C % 16 == 0) hipLaunchKernelGGL(final_kernel<16>, grid, dim3(128), 0, s, S, N, h, w, C, tw, tpp, Wq, bias, out);
+    else if (C % 8 == 0) hipLaunchKernelGGL(final_kernel<8>, grid, dim3(128), 0, s, S, N, h, w, C, tw, tpp, Wq, bias, out);
+    else hipLaunchKernelGGL(final_kernel<4>, grid, dim3(128), 0, s, S, N, h, w, C, tw, tpp, Wq, bias, out);
 }
 
 }  // namespace tmat

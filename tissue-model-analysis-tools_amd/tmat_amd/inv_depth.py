@@ -117,12 +117,15 @@ class InvDepthEnsemble:
         a = np.asarray(stack)
         if a.ndim != 3 or a.dtype not in (np.uint8, np.uint16):
             raise ValueError("predict_stack: expected a (Z, H, W) uint8 or uint16 stack")
+        from .preprocessing import _source_depth
+        src_dtype = a.dtype
         a = np.ascontiguousarray(a, np.uint16)
         ids = np.ascontiguousarray(self.ids, np.int32)
         probs = np.empty((a.shape[0], len(ids)), np.float32)
         x = np.empty((a.shape[0], self.size, self.size, 3), np.float32) if return_input else None
-        check(lib().tmat_inv_depth_predict(self.handle.raw, ptr(ids), len(ids), ptr(a), a.shape[0], a.shape[1], a.shape[2], self.size, ptr(probs),
-                                           ptr(x) if return_input else None), "tmat_inv_depth_predict")
+        with _source_depth(self.handle, src_dtype):          # uint8 slices: cv2's fixed-point bilinear arithmetic (data_prep.py:36)
+            check(lib().tmat_inv_depth_predict(self.handle.raw, ptr(ids), len(ids), ptr(a), a.shape[0], a.shape[1], a.shape[2], self.size, ptr(probs),
+                                               ptr(x) if return_input else None), "tmat_inv_depth_predict")
         return (probs, x) if return_input else probs
 
 

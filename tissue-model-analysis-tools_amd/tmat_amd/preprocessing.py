@@ -21,28 +21,48 @@ def resized_shape(shape, dsamp_size):
     return dsize[1], dsize[0]
 
 
+class _source_depth:
+    """cv2.resize runs uint8 images through its fixed-point bilinear arithmetic and uint16 images through its float arithmetic
+    (oracle/cellarea.py:resize_linear_u8): the entry points take widened uint16 arrays, the handle carries the source depth"""
+
+    def __init__(self, handle: Handle, dtype):
+        self.handle, self.bits = handle, 8 if np.dtype(dtype) == np.uint8 else 16
+
+    def __enter__(self):
+        check(lib().tmat_set_input_depth(self.handle.raw, self.bits), "tmat_set_input_depth")
+
+    def __exit__(self, *exc):
+        check(lib().tmat_set_input_depth(self.handle.raw, 16), "tmat_set_input_depth")
+        return False
+
+
 def cell_area_batch(handle: Handle, imgs: np.ndarray, dsamp_size=512, sd_coef: float = 0.0, return_params=False):
     """imgs (n, H, W) uint8 / uint16 -> (area fractions (n,), thresholded images (n, h, w) uint8 0 / 255[, fit parameters (n, 9)])"""
     a = np.asarray(imgs)
     if a.ndim != 3 or a.dtype not in (np.uint8, np.uint16):
         raise ValueError("cell_area_batch: expected (n, H, W) uint8 or uint16 images")
+    src_dtype = a.dtype
     a = np.ascontiguousarray(a, np.uint16)
     n, H, W = a.shape
     oh, ow = resized_shape((H, W), dsamp_size) if dsamp_size is not None else (0, 0)
     area = np.empty(n, np.float64)
     out = np.empty((n, oh or H, ow or W), np.uint8)
     params = np.empty((n, 9), np.float64)
-    check(lib().tmat_cell_area_batch(handle.raw, ptr(a), n, H, W, oh, ow, float(sd_coef), ptr(area), ptr(out), ptr(params)), "tmat_cell_area_batch")
+    with _source_depth(handle, src_dtype):
+        check(lib().tmat_cell_area_batch(handle.raw, ptr(a), n, H, W, oh, ow, float(sd_coef), ptr(area), ptr(out), ptr(params)), "tmat_cell_area_batch")
     return (area, out, params) if return_params else (area, out)
 
 
 def resize_batch(handle: Handle, imgs: np.ndarray, dsamp_size) -> np.ndarray:
-    """the down-sampling step of load_img (compute_cell_area.py:54-57) for a batch, on the device: (n, H, W) -> (n, h, w) uint16"""
+    """the down-sampling step of load_img (compute_cell_area.py:54-57) for a batch, on the device: (n, H, W) -> (n, h, w) uint16
+    (uint8 sources: cv2's fixed-point arithmetic, values stay <= 255)"""
+    src_dtype = np.asarray(imgs).dtype
     a = np.ascontiguousarray(imgs, np.uint16)
     n, H, W = a.shape
     oh, ow = resized_shape((H, W), dsamp_size)
     out = np.empty((n, oh, ow), np.uint16)
-    check(lib().tmat_resize_linear_u16(handle.raw, ptr(a), n, H, W, oh, ow, ptr(out)), "tmat_resize_linear_u16")
+    with _source_depth(handle, src_dtype):
+        check(lib().tmat_resize_linear_u16(handle.raw, ptr(a), n, H, W, oh, ow, ptr(out)), "tmat_resize_linear_u16")
     return out
 
 

@@ -11,7 +11,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last forward = everything after the last stem_kernel dispatch
-last = max(i for i, r in enumerate(rows) if "stem_kernel" in r["Kernel_Name"])
+last = max(i for i, r in enumerate(rows) if "stem_kernel" in r["Kernel_Name"] or "stem_even_kernel" in r["Kernel_Name"])
 tot = 0
 for r in rows[last:]:
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6

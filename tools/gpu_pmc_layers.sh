@@ -26,7 +26,7 @@ dur = {}
 for r in csv.DictReader(open(sys.argv[2])):
     dur[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 rows = sorted((int(k), v) for k, v in cnt.items())
-last = max(k for k, v in rows if "stem_kernel" in v["name"])
+last = max(k for k, v in rows if "stem_kernel" in v["name"] or "stem_even_kernel" in v["name"])
 for k, v in rows:
     if k < last or sys.argv[3] not in v["name"]:
         continue
