@@ -14,7 +14,7 @@
 #endif
 #if defined(TMAT_VAR_ORDER) || defined(TMAT_VAR_SETPRIO) || defined(TMAT_VAR_NOPIN) || defined(TMAT_OLD_MASKS) || defined(SEP_VAR_MIX) || \
     defined(SEP_VAR_PRIO) || defined(SEP_SPREAD) || defined(SEP_RD_REAL) || defined(SEP_RB_REAL) || defined(SEP_FM_REAL) || \
-    defined(WS_POOL_SHUFFLE)
+    defined(WS_POOL_SHUFFLE) || defined(TMAT_VAR_BUFSTORE)
 #error "a *_VAR_* kernel variant is defined in a product build: variants need -DTMAT_DEV_BUILD (tools/build_variant.sh)"
 #endif
 #if defined(TMAT_DIAG) || defined(WS_DIAG) || defined(SEP_DIAG)

@@ -222,37 +222,53 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
     const int wpass = RP * a.Cin * 4;                // bytes per DMA pass of weight rows
     const int ldsw = wave * 8 * KC;                  // this wave's 8 rows (1 KiB) inside an RP-row pass
 
-    int ld_cb = 0, ld_tap = 0;
+    // Per-tap scalars and per-(tap, pass) lane offsets, made ONCE per tile (round 4).  Rounds 1-3 derived them per chunk from a runtime tap
+    // counter: ~25 scalar instructions (tap -> (dy, dx) -> offsets, wrap) and, per A pass, v_and / v_cmp / v_cndmask to pick the lane's offset
+    // or the out-of-range constant -- 6 vector instructions per chunk next to 16-32 MFMAs, and vector instructions do not issue beside f32
+    // MFMAs.  The K loop below is unrolled over the taps (18 chunks for 3 x 3: two channel blocks, so that the stage parity
+    // repeats; 4 for the sub-pixel form; 2 for 1 x 1), which makes the tap of every DMA a compile-time constant: its scalar offsets are
+    // two s_add, its lane offsets live in registers (taps x NPA <= 18; the kernels use 58-86 of their 128).
+    unsigned pvt[taps][NPA];
+#pragma unroll
+    for (int tp = 0; tp < taps; tp++)
+#pragma unroll
+        for (int i = 0; i < NPA; i++) pvt[tp][i] = ((pm[i] >> tp) & 1u) ? pv[i] : OOB;
+    // scalar offsets of the chunk to load next, advanced by compile-time-selected steps (tap -> next tap in the row, next row, wrap to the
+    // next channel block): A: ((dy + 1) w + dx + 1) Cin + 32 cb floats from the descriptor base; B: tap * wtap + 32 cb
+    const int a_cstep = a.Cin * 4;                                                   // next tap of the same row
+    const int a_rstep = (a.w - (KS == 3 ? 2 : 1)) * a.Cin * 4;                        // first tap of the next row
+    const int a_wrap = KC * 4 - (KS == 3 ? 2 * a.w + 2 : KS == 2 ? a.w + 1 : 0) * a.Cin * 4;      // last tap -> tap 0 of the next channel block
+    const int b_wrap = KC * 4 - (taps - 1) * wtap;
+    int soA = (KS == 3 ? 0 : KS == 2 ? spy * a.w + spx : a.w + 1) * a.Cin * 4, soB = 0, soBp = 0;
 #ifdef TMAT_ABL_A9        // timing ablation (wrong results): the A tile is fetched for one tap per channel block only -- what a halo tile could save at most
-#define TMAT_ABL_A9_COND (ld_tap == 0)
+#define TMAT_ABL_A9_COND(T_) ((T_) == 0)
 #else
-#define TMAT_ABL_A9_COND true
+#define TMAT_ABL_A9_COND(T_) true
 #endif
-#define TMAT_DMA_A(i)                                                                                        \
-    if (i < NPA) {                                                                                           \
-        const unsigned vo = (pm[i] & tbit) ? pv[i] : OOB;                                                    \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t *)(st + i * RP * KC + ldsw), 16, vo, soA, 0, 0); \
+#define TMAT_DMA_A(i, T_)                                                                                    \
+    if (i < NPA) {        /* (the offset through a local: with pvt[T_][i] as the argument itself, the HOST pass silently drops the kernel's stub) */ \
+        const unsigned vo_ = pvt[T_][i];                                                                     \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t *)(st + i * RP * KC + ldsw), 16, vo_, soA, 0, 0); \
     }
 #define TMAT_DMA_B(i)                                                                                        \
     if (PREC == 0 && i < NPB)                                                                                \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t *)(st + (BM + i * RP) * KC + ldsw), 16, wv, soB + i * wpass, 0, 0); \
     if (PREC != 0 && i < NPL && wave * 16 < BN)      /* plane i: this wave's 16 rows of 64 bytes */          \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t *)(st + BM * KC + i * BN * 16 + wave * 256), 16, wvp, soBp + i * plane_bytes, 0, 0);
-#define TMAT_ISSUE_CHUNK(stage_)                                                       \
+// T_: the tap of the chunk being loaded -- a compile-time constant at every use (the K loop is unrolled over the taps)
+#define TMAT_ISSUE_CHUNK(stage_, T_)                                                   \
     {                                                                                  \
         float *st = (stage_);                                                          \
-        const int dy = KS == 3 ? ld_tap / 3 - 1 : KS == 2 ? spy - 1 + (ld_tap >> 1) : 0; \
-        const int dx = KS == 3 ? ld_tap % 3 - 1 : KS == 2 ? spx - 1 + (ld_tap & 1) : 0;  \
-        const int soA = (((dy + 1) * a.w + dx + 1) * a.Cin + ld_cb * KC) * 4;          \
-        const int soB = ld_tap * wtap + ld_cb * KC * 4;                                \
-        const int soBp = ld_tap * (wtap >> 1) + ld_cb * KC * 2;      /* bf16 planes */     \
-        const unsigned tbit = 1u << ld_tap;                                            \
-        if (TMAT_ABL_A9_COND) {                                                        \
-        TMAT_DMA_A(0) TMAT_DMA_A(1) TMAT_DMA_A(2) TMAT_DMA_A(3)                        \
-        TMAT_DMA_A(4) TMAT_DMA_A(5) TMAT_DMA_A(6) TMAT_DMA_A(7)                        \
+        if (TMAT_ABL_A9_COND(T_)) {                                                    \
+        TMAT_DMA_A(0, T_) TMAT_DMA_A(1, T_) TMAT_DMA_A(2, T_) TMAT_DMA_A(3, T_)        \
+        TMAT_DMA_A(4, T_) TMAT_DMA_A(5, T_) TMAT_DMA_A(6, T_) TMAT_DMA_A(7, T_)        \
         }                                                                              \
         TMAT_DMA_B(0) TMAT_DMA_B(1) TMAT_DMA_B(2) TMAT_DMA_B(3)                        \
-        if (++ld_tap == taps) { ld_tap = 0; ld_cb++; }                                 \
+        if ((T_) == taps - 1) { soA += a_wrap; soB += b_wrap; soBp += (b_wrap >> 1); } \
+        else {                                                                         \
+            soA += (KS == 3 ? (T_) % 3 == 2 : KS == 2 ? ((T_) & 1) == 1 : false) ? a_rstep : a_cstep; \
+            soB += wtap; soBp += (wtap >> 1);                                          \
+        }                                                                              \
     }
 
     f32x16 acc[TM][TN];
@@ -286,9 +302,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
 #define TMAT_PIN() __builtin_amdgcn_sched_barrier(0);
 #endif
 #ifdef TMAT_ABL_NODMA
-#define TMAT_LOOP_ISSUE(st)
+#define TMAT_LOOP_ISSUE(st, T_)
 #else
-#define TMAT_LOOP_ISSUE(st) TMAT_ISSUE_CHUNK(st)
+#define TMAT_LOOP_ISSUE(st, T_) TMAT_ISSUE_CHUNK(st, T_)
 #endif
 #ifdef TMAT_ABL_NOBAR
 #define TMAT_LOOP_SYNC()
@@ -339,20 +355,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
 // in the shipped build.)
 #define R_(c_, g) TMAT_READ_FRAGS_RANGE(c_, g, g + 1) TMAT_PIN()
 #define M_(g) TMAT_MFMAS_RANGE(g, g + 1) TMAT_PIN()
-#define D_(n_, m_) if (m_) TMAT_LOOP_ISSUE(n_) TMAT_PIN()
+#define D_(n_, m_, T_) if (m_) TMAT_LOOP_ISSUE(n_, T_) TMAT_PIN()
 #if defined(TMAT_VAR_ORDER) && TMAT_VAR_ORDER == 0       // the round-2 order
-#define TMAT_ORDER(c_, n_, m_) R_(c_, 0) R_(c_, 1) R_(c_, 2) R_(c_, 3) D_(n_, m_) M_(0) M_(1) M_(2) M_(3)
+#define TMAT_ORDER(c_, n_, m_, T_) R_(c_, 0) R_(c_, 1) R_(c_, 2) R_(c_, 3) D_(n_, m_, T_) M_(0) M_(1) M_(2) M_(3)
 #elif defined(TMAT_VAR_ORDER) && TMAT_VAR_ORDER == 2
-#define TMAT_ORDER(c_, n_, m_) R_(c_, 0) R_(c_, 1) M_(0) D_(n_, m_) R_(c_, 2) M_(1) R_(c_, 3) M_(2) M_(3)
+#define TMAT_ORDER(c_, n_, m_, T_) R_(c_, 0) R_(c_, 1) M_(0) D_(n_, m_, T_) R_(c_, 2) M_(1) R_(c_, 3) M_(2) M_(3)
 #elif defined(TMAT_VAR_ORDER) && TMAT_VAR_ORDER == 3
-#define TMAT_ORDER(c_, n_, m_) R_(c_, 0) M_(0) R_(c_, 1) D_(n_, m_) M_(1) R_(c_, 2) M_(2) R_(c_, 3) M_(3)
+#define TMAT_ORDER(c_, n_, m_, T_) R_(c_, 0) M_(0) R_(c_, 1) D_(n_, m_, T_) M_(1) R_(c_, 2) M_(2) R_(c_, 3) M_(3)
 #else
-#define TMAT_ORDER(c_, n_, m_) R_(c_, 0) R_(c_, 1) M_(0) R_(c_, 2) D_(n_, m_) M_(1) R_(c_, 3) M_(2) M_(3)
+#define TMAT_ORDER(c_, n_, m_, T_) R_(c_, 0) R_(c_, 1) M_(0) R_(c_, 2) D_(n_, m_, T_) M_(1) R_(c_, 3) M_(2) M_(3)
 #endif
-#define TMAT_STEP(cur, nxt, more)                                                      \
+#define TMAT_STEP(cur, nxt, more, T_)                                                  \
     {                                                                                  \
         float4 av[4][TM], bv[4][TN];                                                   \
-        TMAT_ORDER(cur, nxt, more)                                                     \
+        TMAT_ORDER(cur, nxt, more, T_)                                                 \
         TMAT_LOOP_SYNC()                                                               \
     }
 
@@ -360,7 +376,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
     // 16 tk + 8 h + j (A: 16-byte units 4 tk + 2 h, 4 tk + 2 h + 1 of its f32 row; B: unit 2 tk + h of its row in every plane)
     const int browp = BM * KC + (wn * (BN / WN) + (lane & 31)) * 16;
     const int keyb = (lane >> 2) & 3;
-#define TMAT_STEP_BF16(cur, nxt, more)                                                 \
+#define TMAT_STEP_BF16(cur, nxt, more, T_)                                             \
     {                                                                                  \
         float4 af[2][TM][2];                                                           \
         _Pragma("unroll") for (int tk = 0; tk < 2; tk++) {                             \
@@ -379,12 +395,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
         TMAT_PIN()                                                                     \
         /* the next chunk's DMA: six products -- behind the first k step's MFMAs, as in the f32 step (209.8 -> 204.3 ms per pass); three */ \
         /* products -- in front (a chunk is only 384 cycles of matrix time per wave: issued later, the DMA lands late: +4 ms per pass) */ \
-        if (NPL == 2) { if (more) TMAT_LOOP_ISSUE(nxt) }                               \
+        if (NPL == 2) { if (more) TMAT_LOOP_ISSUE(nxt, T_) }                           \
         TMAT_PIN()                                                                     \
         _Pragma("unroll") for (int tk = 0; tk < 2; tk++) {                             \
             if (NPL == 3 && tk == 1) {                                                 \
                 TMAT_PIN()                                                             \
-                if (more) TMAT_LOOP_ISSUE(nxt)                                         \
+                if (more) TMAT_LOOP_ISSUE(nxt, T_)                                     \
                 TMAT_PIN()                                                             \
             }                                                                          \
             if (NPL == 3 && tk == 1) {                                                 \
@@ -427,7 +443,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
     long long dg_work = 0, dg_vm = 0, dg_bar = 0;
     const long long dg_t0 = (long long)__builtin_readcyclecounter();
 #endif
-    TMAT_ISSUE_CHUNK(stage0)
+    TMAT_ISSUE_CHUNK(stage0, 0)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifdef TMAT_DIAG
@@ -435,16 +451,27 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
     const long long dg_fill = dg_last - dg_t0;
 #endif
 
-    // even chunks live in stage0, odd ones in stage1 (nchunks is even: host check)
+    // even chunks live in stage0, odd ones in stage1.  The loop body is UNR chunks, unrolled: UNR is the smallest even multiple of the tap
+    // count (nchunks = taps x Cin / 32 is a multiple of it: host check), so chunk c + u has tap u % taps and stage u & 1, and the DMA issued
+    // in its step is that of chunk c + u + 1: tap (u + 1) % taps, at compile time.
+    constexpr int UNR = (taps & 1) ? 2 * taps : taps;
     if (PREC == 0) {
-        for (int c = 0; c < nchunks; c += 2) {
-            TMAT_STEP(stage0, stage1, true)                 // chunk c; DMA of chunk c + 1
-            TMAT_STEP(stage1, stage0, c + 2 < nchunks)      // chunk c + 1; DMA of chunk c + 2
+        for (int c = 0; c < nchunks; c += UNR) {
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const bool more = u + 1 < UNR || c + UNR < nchunks;
+                if (u & 1) TMAT_STEP(stage1, stage0, more, (u + 1) % taps)
+                else TMAT_STEP(stage0, stage1, more, (u + 1) % taps)
+            }
         }
     } else {
-        for (int c = 0; c < nchunks; c += 2) {
-            TMAT_STEP_BF16(stage0, stage1, true)
-            TMAT_STEP_BF16(stage1, stage0, c + 2 < nchunks)
+        for (int c = 0; c < nchunks; c += UNR) {
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const bool more = u + 1 < UNR || c + UNR < nchunks;
+                if (u & 1) TMAT_STEP_BF16(stage1, stage0, more, (u + 1) % taps)
+                else TMAT_STEP_BF16(stage0, stage1, more, (u + 1) % taps)
+            }
         }
     }
 #undef TMAT_STEP_BF16
@@ -502,14 +529,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
             }
         const int quad = lane % V4W, rsub = lane / V4W;
         const int co = n0 + wn * (BN / WN) + quad * 4;
-        float4 sc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // no scale (plain bias): fmaf(v, 1, shift) is v + shift bit for bit (the product is exact, one rounding), so the loop below has ONE
+        // form -- with `a.scale ? fmaf : add` hipcc evaluated both and selected per value (2 v_pk_add + 4 v_cndmask per 16-byte row, and
+        // every vector instruction of an f32-MFMA kernel is matrix time: DESIGN 4)
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
         const float4 sh = *reinterpret_cast<const float4 *>(a.shift + co);
         if (a.scale) sc = *reinterpret_cast<const float4 *>(a.scale + co);
         const int rH = Ho >> a.rs, rW = Wo >> a.rs;
         const int mw = m0 + wm * (BM / WM);                  // first output pixel of the wave's block
         const bool full = mw + WROWS <= M;
         const unsigned vo = (unsigned)(rsub * a.Cout + quad * 4) * 4u;
-        const float relu_lo = a.relu_out ? 0.f : -__builtin_inff();
         const size_t tbase = (size_t)mw * a.Cout + n0 + wn * (BN / WN);
         char *const obase = reinterpret_cast<char *>(a.out + tbase);
         char *const o2base = reinterpret_cast<char *>(a.out_relu + tbase);                // used when a.out_relu only
@@ -521,8 +550,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
             const bool ok = full || m < M;
             const size_t so = (size_t)(it * RPW) * a.Cout * 4;
             float4 v = *reinterpret_cast<const float4 *>(Ws + row * WCOLS + quad * 4);
-            if (a.scale) { v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w); }
-            else { v.x = v.x + sh.x; v.y = v.y + sh.y; v.z = v.z + sh.z; v.w = v.w + sh.w; }
+            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
             if (a.resid) {
                 float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (a.rs) {
@@ -536,7 +564,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
                 } else if (ok) rv = *reinterpret_cast<const float4 *>(rbase + so + vo);
                 v.x = v.x + rv.x; v.y = v.y + rv.y; v.z = v.z + rv.z; v.w = v.w + rv.w;
             }
-            v.x = fmaxf(v.x, relu_lo); v.y = fmaxf(v.y, relu_lo); v.z = fmaxf(v.z, relu_lo); v.w = fmaxf(v.w, relu_lo);
+            if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }      // uniform branch
             if (KS == 2) {      // scatter to the parity class's pixels of the (2 Ho, 2 Wo) output
                 if (ok) {
                     const int n = fdiv(m, dHW);
@@ -547,7 +575,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
                 }
             }
             else if (ok) {
+#ifdef TMAT_VAR_BUFSTORE       // round-3 incident (ii): the rows through raw_buffer_store_b128 (tile in the descriptor, iteration in soffset); see DESIGN "Incidents"
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v),
+                                                       __builtin_amdgcn_make_buffer_rsrc((void *)obase, 0, 0x7fffffff, 0x00020000), vo, (int)so, 0);
+#else
                 *reinterpret_cast<float4 *>(obase + so + vo) = v;
+#endif
                 // the activated copy for the next block's first convolution (uniform branch): four v_max per 16-byte store here instead of
                 // sixteen v_max_i32 per K chunk and wave in the consumer's RELU instantiation (0.7 ms per launch)
                 if (a.out_relu) {       // relu_pos0: negative values and -0.0 become +0.0, exactly what the RELU instantiation's load-side max does
@@ -635,7 +668,7 @@ bool launch_conv(const ConvArgs &a, hipStream_t s)
     const long long Mll = (long long)a.N * Ho * Wo;
     if (!((a.ksize == 3 && a.stride == 1) || (a.ksize == 2 && a.stride == 1 && !a.resid) ||
           (a.ksize == 1 && (a.stride == 1 || a.stride == 2))) || a.Cin % 32 || a.Cout % 64 ||
-        ((a.ksize * a.ksize * (a.Cin / 32)) & 1) || Mll <= 0 ||
+        ((a.ksize == 2 ? 4 : a.ksize * a.ksize) * (a.Cin / 32)) % ((a.ksize & 1) ? 2 * a.ksize * a.ksize : 4) || Mll <= 0 ||
         Mll > 0x7fffffffLL / 2 || (a.resid && a.rs && ((Ho | Wo) & 1)) || Wo < 2 || (a.out_relu && a.ksize == 2)) {
         set_error("launch_conv: unsupported shape");
         return false;
