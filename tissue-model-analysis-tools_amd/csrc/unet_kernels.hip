@@ -344,7 +344,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
                 }                                                                      \
         }
 // Order of one step (R = the fragment reads of a k group: TM + TN ds_read_b128, M = its 8 TM TN MFMAs, D = the LDS-DMA of the next chunk):
-//     R0 R1 M0 R2 D M1 R3 M2 M3      then the wave's vmcnt(0) and the workgroup barrier.
+//     R0 M0 D R1 M1 R2 M2 R3 M3      then the wave's vmcnt(0) and the workgroup barrier            (round 4)
+//     R0 R1 M0 R2 D M1 R3 M2 M3      was round 3's order (TMAT_VAR_ORDER=1).  With the K loop unrolled over the taps the DMA issue is four
+//     s_mov m0 / buffer_load pairs and nothing else, and reads one group ahead are enough: measured per pass of 1600 patches (network
+//     kernels) 241.1 (round-3 order) / 239.8 (R0 M0 R1 D M1 ..) / 239.2 (this) / 239.3 (R0 D M0 R1 ..) / 240.2 (D behind M1) / 240.1 (D first).
 // After a barrier all eight waves of a workgroup stand at the same instruction, so whatever comes first is what the matrix pipe waits
 // for unless the CU's other workgroup happens to be in its MFMA stretch.  Round 1-2 issued all sixteen reads, then the DMA (4 instructions
 // + ~30 scalar ones per wave), then the 32 MFMAs: the first MFMA of the LAST wave waited for 8 x 16 KB of reads to drain through the LDS
@@ -362,8 +365,18 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
 #define TMAT_ORDER(c_, n_, m_, T_) R_(c_, 0) R_(c_, 1) M_(0) D_(n_, m_, T_) R_(c_, 2) M_(1) R_(c_, 3) M_(2) M_(3)
 #elif defined(TMAT_VAR_ORDER) && TMAT_VAR_ORDER == 3
 #define TMAT_ORDER(c_, n_, m_, T_) R_(c_, 0) M_(0) R_(c_, 1) D_(n_, m_, T_) M_(1) R_(c_, 2) M_(2) R_(c_, 3) M_(3)
-#else
+#elif defined(TMAT_VAR_ORDER) && TMAT_VAR_ORDER == 1       // the round-3 order
 #define TMAT_ORDER(c_, n_, m_, T_) R_(c_, 0) R_(c_, 1) M_(0) R_(c_, 2) D_(n_, m_, T_) M_(1) R_(c_, 3) M_(2) M_(3)
+#elif defined(TMAT_VAR_ORDER) && TMAT_VAR_ORDER == 5
+#define TMAT_ORDER(c_, n_, m_, T_) R_(c_, 0) R_(c_, 1) M_(0) D_(n_, m_, T_) M_(1) R_(c_, 2) M_(2) R_(c_, 3) M_(3)
+#elif defined(TMAT_VAR_ORDER) && TMAT_VAR_ORDER == 6
+#define TMAT_ORDER(c_, n_, m_, T_) R_(c_, 0) D_(n_, m_, T_) M_(0) R_(c_, 1) M_(1) R_(c_, 2) M_(2) R_(c_, 3) M_(3)
+#elif defined(TMAT_VAR_ORDER) && TMAT_VAR_ORDER == 7
+#define TMAT_ORDER(c_, n_, m_, T_) R_(c_, 0) M_(0) R_(c_, 1) M_(1) D_(n_, m_, T_) R_(c_, 2) M_(2) R_(c_, 3) M_(3)
+#elif defined(TMAT_VAR_ORDER) && TMAT_VAR_ORDER == 8
+#define TMAT_ORDER(c_, n_, m_, T_) D_(n_, m_, T_) R_(c_, 0) M_(0) R_(c_, 1) M_(1) R_(c_, 2) M_(2) R_(c_, 3) M_(3)
+#else
+#define TMAT_ORDER(c_, n_, m_, T_) R_(c_, 0) M_(0) D_(n_, m_, T_) R_(c_, 1) M_(1) R_(c_, 2) M_(2) R_(c_, 3) M_(3)
 #endif
 #define TMAT_STEP(cur, nxt, more, T_)                                                  \
     {                                                                                  \
