@@ -58,13 +58,17 @@ def rescale_0_255_u8(im: np.ndarray) -> np.ndarray:
     return np.clip(im, 0.0, 255.0).astype(np.float64).astype(np.uint8)
 
 
-def threshold_otsu_u8(im: np.ndarray):
-    """filters/thresholding.py:threshold_otsu on an integer image"""
+def threshold_otsu_u8(im: np.ndarray, counts_dtype=np.float64):
+    """filters/thresholding.py:threshold_otsu on an integer image.  counts_dtype: scikit-image 0.18.3 (the version the goldens were
+    generated with, and what the device evaluates) turns the histogram counts into float64; from 0.19 on -- the reference pins 0.22.0 --
+    _validate_image_histogram casts them to float32 before the cumulative sums (recalled from the published source: 0.22 is not
+    importable here).  Passing np.float32 evaluates that form; tests/test_oracle_wellmask.py asserts both pick the same threshold on
+    every fixture case (a near-tie of the between-class variance could separate them: parity against 0.22 is unpinned there)."""
     first = im.ravel()[0]
     if np.all(im == first):
         return first
     lo, hi = int(im.min()), int(im.max())
-    counts = np.bincount(im.ravel(), minlength=hi + 1)[lo:hi + 1].astype(float)
+    counts = np.bincount(im.ravel(), minlength=hi + 1)[lo:hi + 1].astype(counts_dtype)
     centers = np.arange(lo, hi + 1)
     w1 = np.cumsum(counts)
     w2 = np.cumsum(counts[::-1])[::-1]

@@ -833,25 +833,26 @@ __global__ __launch_bounds__(256) void stem_kernel(const float *__restrict__ x, 
 // recomputed inside the first separable convolution's depthwise producers (sepconv_ws_kernel<..., STEM>), the only other reader of the
 // stem tensor is block 0's 1x1 / stride-2 residual convolution (models.py:140), which samples exactly these pixels: a quarter of the
 // tensor (2.6 instead of 10.5 GB per pass of 1600 patches) and a unit-stride 1x1 convolution behind it.  Same chain as stem_kernel.
+constexpr int SE_PX = 4;        // output pixels per thread (measured on one box: 4 pixels 1.05 ms, 2 pixels -- fewer registers, more waves -- 1.22 ms)
 __global__ __launch_bounds__(256) void stem_even_kernel(const float *__restrict__ x, int H, int W, const float *__restrict__ Ws,
                                                         int Cout, int c4shift, const float *__restrict__ scale,
                                                         const float *__restrict__ shift, float *__restrict__ out)
 {
-    // One thread = 4 consecutive output pixels of a row x 4 channels: the 3 rows x 16 input columns they touch (columns 16 g .. 16 g + 14)
-    // as 12 aligned 16-byte loads shared by the 16 channel-quad lanes of a pixel group, the taps and the folded BN once per thread.
-    const int Ho = H >> 2, Wo = W >> 2, WG = Wo >> 2;           // (W / 4) % 4 == 0: the patch size is a multiple of 64
+    // One thread = SE_PX consecutive output pixels of a row x 4 channels: the 3 rows x 4 SE_PX input columns they touch as aligned
+    // 16-byte loads shared by the 16 channel-quad lanes of a pixel group, the taps and the folded BN once per thread.
+    const int Ho = H >> 2, Wo = W >> 2, WG = Wo / SE_PX;        // (W / 4) % 4 == 0: the patch size is a multiple of 64
     const int n = blockIdx.y;
     const int e = blockIdx.x * 256 + threadIdx.x;
     const int cq = e & ((1 << c4shift) - 1);
     const int g = e >> c4shift;
     if (g >= Ho * WG) return;
     const int yo = g / WG, xg = g - yo * WG;
-    const float *xin = x + (size_t)n * H * W + (size_t)(4 * yo) * W + 16 * xg;      // rows 4 yo .. 4 yo + 2 < H, columns 16 xg .. 16 xg + 15 < W
-    float win[3][16];
+    const float *xin = x + (size_t)n * H * W + (size_t)(4 * yo) * W + 4 * SE_PX * xg;      // rows 4 yo .. 4 yo + 2 < H, columns < W
+    float win[3][4 * SE_PX];
 #pragma unroll
     for (int r = 0; r < 3; r++)
 #pragma unroll
-        for (int c4 = 0; c4 < 4; c4++) {
+        for (int c4 = 0; c4 < SE_PX; c4++) {
             const float4 v = *reinterpret_cast<const float4 *>(xin + r * W + c4 * 4);
             win[r][c4 * 4] = v.x; win[r][c4 * 4 + 1] = v.y; win[r][c4 * 4 + 2] = v.z; win[r][c4 * 4 + 3] = v.w;
         }
@@ -860,9 +861,9 @@ __global__ __launch_bounds__(256) void stem_even_kernel(const float *__restrict_
     for (int tp = 0; tp < 9; tp++) wt[tp] = *reinterpret_cast<const float4 *>(Ws + tp * Cout + cq * 4);
     const float4 sc = *reinterpret_cast<const float4 *>(scale + cq * 4);
     const float4 sh = *reinterpret_cast<const float4 *>(shift + cq * 4);
-    float *obase = out + ((size_t)n * Ho * Wo + (size_t)yo * Wo + 4 * xg) * Cout + cq * 4;
+    float *obase = out + ((size_t)n * Ho * Wo + (size_t)yo * Wo + SE_PX * xg) * Cout + cq * 4;
 #pragma unroll
-    for (int px = 0; px < 4; px++) {
+    for (int px = 0; px < SE_PX; px++) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int tp = 0; tp < 9; tp++) {
@@ -879,7 +880,7 @@ __global__ __launch_bounds__(256) void stem_even_kernel(const float *__restrict_
 void launch_stem_even(const float *x, int N, int H, int W, const float *Ws, int Cout, const float *scale,
                       const float *shift, float *out, hipStream_t s)
 {
-    const int total = (H / 4) * (W / 16) * (Cout / 4);
+    const int total = (H / 4) * (W / 4 / SE_PX) * (Cout / 4);
     hipLaunchKernelGGL(stem_even_kernel, dim3((total + 255) / 256, N), dim3(256), 0, s, x, H, W, Ws, Cout, ilog2(Cout / 4), scale, shift, out);
 }
 
@@ -977,8 +978,9 @@ __global__ __launch_bounds__(128) void final_kernel(const float *__restrict__ S,
                                                     const float *__restrict__ Wq, float bias, float *__restrict__ out)
 {
     // The channels go through LDS in blocks of CB (the chain order -- 4-channel groups ascending -- is unchanged, the four
-    // accumulators live in registers across the blocks): with CB = 32 a workgroup holds 28 KiB instead of 49, five of them
-    // fit a CU instead of three, and the fill of one overlaps the arithmetic of the others.
+    // accumulators live in registers across the blocks): a workgroup holds 15 KiB at CB = 16 (28 at 32, 49 for all 64 channels),
+    // so eight of them (16 waves) fit a CU and the fill of one overlaps the arithmetic of the others; the kernel then runs at the
+    // streaming rate of its 11.1 GB of reads (4.4 TB/s).
     constexpr int CP = CB + 4, B4 = CB / 4;
     constexpr int RPITCH = ((18 * CP + 63) / 64) * 64;
     static_assert((B4 & (B4 - 1)) == 0, "channel quads per block: a power of two");
@@ -1056,7 +1058,7 @@ void launch_final(const float *S, int N, int h, int w, int C, const float *Wq, f
     const dim3 grid((unsigned)(((N + 7) / 8) * 8 * tpp));           // N <= max_patches and tpp = 200 at 160 x 160: far below 2^31
     // channels per LDS block: 32 when the channel count allows (every shipped model: C = 64), else 16 / 8 / 4 (C % 4 == 0: tmat_create)
 #ifndef TMAT_FINAL_CB
-#define TMAT_FINAL_CB 32
+#define TMAT_FINAL_CB 16    // measured per launch of 1600 patches: 16 channels per LDS block 2.51 ms (15 KB of LDS: 8 workgroups = 16 waves per CU), 32: 3.22 ms (5 workgroups), 8: 4.16 ms
 #endif
     if (C % 32 == 0) hipLaunchKernelGGL(final_kernel<TMAT_FINAL_CB>, grid, dim3(128), 0, s, S, N, h, w, C, tw, tpp, Wq, bias, out);
     else if (C % 16 == 0) hipLaunchKernelGGL(final_kernel<16>, grid, dim3(128), 0, s, S, N, h, w, C, tw, tpp, Wq, bias, out);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile bundle (run on the GPU box through gpurun): default bench line, rocprofv3 --kernel-trace --stats of
 # the same command, and separate PMC passes (FETCH_SIZE / WRITE_SIZE / MFMA busy) on a short run of the same pipeline.
-# Usage: bash tools/profile_round.sh r01
+# Usage: bash tools/profile_round.sh r01 [no-pmc | pmc-only]      (two calls when one does not fit the gpurun time limit)
 set -e
 R=${1:-r01}
 ROOT=$GRAFT_REPO_ROOT
@@ -17,6 +17,7 @@ find $OUT/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kern
 rm -rf $OUT/trace            # the raw per-dispatch trace is large; the stats summary is what is kept
 echo "kernel-trace done"
 fi
+if [ "$2" = "no-pmc" ]; then ls -la $OUT; exit 0; fi
 # PMC passes (separate runs, --kernel-trace only beside --pmc) on the UNet forward alone: the same kernels with the same
 # 1600-patch launches as in the pipeline (tools/gpu_quick.py), without the many short morphology / thinning launches,
 # each of which costs milliseconds under counter collection
