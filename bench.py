@@ -330,7 +330,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "tmat::conv_mfma_kernel<128, 128, 4, 2, 3, false> (3x3 implicit-GEMM on v_mfma_f32_32x32x2_f32; "
-                                   "3 of the 8 transposed-conv layers, 39 % of the 3x3 / sub-pixel MFMA FLOPs; the largest kernel by total time)",
+                                   "4 of the 8 transposed-conv layers -- both convolutions of up block 0 and the second one of blocks 1 and 2 --, "
+                                   "52 % of the 3x3 / sub-pixel MFMA FLOPs; the largest kernel by total time)",
                          "launches": int(conv_launches), "avg_launch_ms": round(conv_ms / max(conv_launches, 1), 4),
                          "timed_in": f"separate pass of {n_prof} images after the timed region (HIP events on the launch stream)",
                          "path_achieved": round(path_tflops, 2), "path_frac": round(path_tflops / MFMA_F32_PEAK_TFLOPS, 4),

@@ -424,7 +424,7 @@ int tmat_set_input_norm(tmat_handle h, int on, double norm_mean, double norm_std
 /*
  * Timing hook for bench.py's roofline line: accumulated HIP-event time (ms) and launch count of
  * the dominant kernel -- tmat::conv_mfma_kernel<128, 128, 4, 2, 3, false>, the 3x3 implicit-GEMM MFMA
- * convolution instantiation that runs 3 of the 8 transposed-conv layers -- since the last reset, measured
+ * convolution instantiation that runs 4 of the 8 transposed-conv layers -- since the last reset, measured
  * on the stream it is launched on.  flops = algorithmic FLOPs of those launches.
  */
 int tmat_prof_enable(tmat_handle h, int on);

@@ -23,7 +23,7 @@ def test_every_declared_symbol_is_exported():
 
 
 @pytest.mark.parametrize("src, flag", [("unet_kernels.hip", "TMAT_ABL_A9"), ("unet_kernels.hip", "TMAT_VAR_ORDER=2"),
-                                       ("sepconv_ws_kernels.hip", "WS_DIAG"), ("sepconv_kernels.hip", "SEP_ABL_NOMFMA")])
+                                       ("sepconv_ws_kernels.hip", "WS_DIAG"), ("unet_kernels.hip", "TMAT_VAR_BUFSTORE")])
 def test_product_builds_refuse_ablation_and_variant_flags(src, flag):
     """a wrong-result ablation (or a variant / diagnostic switch) cannot reach a product build: csrc/dev_guard.h stops the compile
     unless -DTMAT_DEV_BUILD is given, which only tools/build_variant.sh passes (its output goes to build_variants/)"""

@@ -7,17 +7,14 @@
 // compile of libtmat_hip.so stops here.
 #pragma once
 #if !defined(TMAT_DEV_BUILD)
-#if defined(TMAT_ABL_A9) || defined(TMAT_ABL_NOEPI) || defined(TMAT_ABL_NODMA) || defined(TMAT_ABL_NOBAR) || \
-    defined(SEP_ABL_VMCNT) || defined(SEP_ABL_NORD) || defined(SEP_ABL_NORB) || defined(SEP_ABL_NOMFMA) || defined(SEP_ABL_NODW) || \
-    defined(SEP_ABL_NODMA)
+#if defined(TMAT_ABL_A9) || defined(TMAT_ABL_NOEPI) || defined(TMAT_ABL_NODMA) || defined(TMAT_ABL_NOBAR)
 #error "an *_ABL_* timing ablation (wrong results) is defined in a product build: ablations need -DTMAT_DEV_BUILD (tools/build_variant.sh)"
 #endif
-#if defined(TMAT_VAR_ORDER) || defined(TMAT_VAR_SETPRIO) || defined(TMAT_VAR_NOPIN) || defined(TMAT_OLD_MASKS) || defined(SEP_VAR_MIX) || \
-    defined(SEP_VAR_PRIO) || defined(SEP_SPREAD) || defined(SEP_RD_REAL) || defined(SEP_RB_REAL) || defined(SEP_FM_REAL) || \
+#if defined(TMAT_VAR_ORDER) || defined(TMAT_VAR_SETPRIO) || defined(TMAT_VAR_NOPIN) || defined(TMAT_OLD_MASKS) || \
     defined(WS_POOL_SHUFFLE) || defined(TMAT_VAR_BUFSTORE)
 #error "a *_VAR_* kernel variant is defined in a product build: variants need -DTMAT_DEV_BUILD (tools/build_variant.sh)"
 #endif
-#if defined(TMAT_DIAG) || defined(WS_DIAG) || defined(SEP_DIAG)
+#if defined(TMAT_DIAG) || defined(WS_DIAG)
 #error "a *_DIAG cycle-stamp build is not a product build: diagnostics need -DTMAT_DEV_BUILD (tools/build_variant.sh)"
 #endif
 #endif

@@ -4,11 +4,11 @@
 // block, MaxPooling2D(3, 2, "same") + residual add behind the second one), executed by keras Model.predict at
 // smooth_tiled_predictions.py:179.
 //
-// sepconv_kernels.hip computes the depthwise values inside the MFMA waves (each lane builds its own A fragment between
-// its MFMAs); its counters show the matrix pipe busy 0.53-0.65 of the time: the in-order waves cannot overlap their own
-// vector work, LDS reads and LDS-DMA issue with their own MFMAs.  Here the two kinds of work live in DIFFERENT waves of
-// one 12-wave workgroup, which the four SIMDs of a CU run side by side (the matrix pipe and the vector ALU of a SIMD
-// issue from different waves in the same cycles):
+// Round 2's fused kernel (removed in round 4; git history: csrc/sepconv_kernels.hip) computed the depthwise values inside the MFMA
+// waves (each lane built its own A fragment between its MFMAs); its counters showed the matrix pipe busy 0.53-0.65 of the time: the
+// in-order waves cannot overlap their own vector work, LDS reads and LDS-DMA issue with their own MFMAs.  Here the two kinds of work
+// live in DIFFERENT waves of one 12-wave workgroup (phases: see below -- the f32 MFMA and the vector ALU of a SIMD do not issue in
+// the same cycles, so a step has an MFMA phase and a vector phase):
 //   waves 0-7  consumers: a 16 x 16 pixel tile (M = 256) x 128 output channels on v_mfma_f32_32x32x2_f32; wave w owns
 //              tile rows 2w, 2w+1 as four 32x32 accumulators.  Per 32-channel step: 20 ds_read_b128, 64 MFMAs, one
 //              barrier.  No vector-memory instruction except the tile's stores.
@@ -20,7 +20,7 @@
 //              bank swizzle, (4) issues the LDS-DMA of the next step's pointwise weights and of its own next halo.
 // Two A / B stages; the halo region is single (a producer refills it after its last read of the step).
 //
-// Arithmetic contract: identical to sepconv_kernels.hip and to oracle/unet_exact.c:orc_dwconv -> orc_conv (depthwise
+// Arithmetic contract: identical to the unfused pair dwconv_kernel -> conv_mfma_kernel<.., 1, ..> and to oracle/unet_exact.c:orc_dwconv -> orc_conv (depthwise
 // chain over the 9 taps in (ky, kx) order from +0.0, zero padding, optional ReLU on load; pointwise chain over the
 // input channels in groups of 8 in the order 0,4,1,5,2,6,3,7; epilogue fmaf(acc, scale, shift), optional ReLU; the
 // pooled form: max, then one add).  tests/test_gpu_unet.py compares bits.
@@ -55,7 +55,8 @@ struct WsArgs {
     const float *pwk;     // pointwise weights [Cout][Cin] (k contiguous)
     const float *scale, *shift;
     int relu_out;
-    float *out;           // (N, H, W, Cout); POOL: (N, H/2, W/2, Cout), see sepconv_kernels.hip:SepArgs
+    float *out;           // (N, H, W, Cout); POOL: (N, H/2, W/2, Cout): complete pooled pixels with their residual; a tile's last pooled row / column
+                          // are left as partial maxima for pool_fix_add_kernel
     const float *resid;   // POOL only
     float *strip_h, *strip_v, *corner;      // POOL only (pool_fix_add_kernel finishes the tile edges)
     const float *stem_w, *stem_scale, *stem_shift;      // STEM only: `in` is then the (N, 2H, 2W) single-channel patch; taps [9][Cin], folded BN
@@ -97,7 +98,9 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
 {
     __shared__ __attribute__((aligned(16))) float smem[STEM ? WS_TOTAL_STEM : WS_TOTAL];
 
-    // persistent ranges as in sepconv_mfma_kernel: an XCD gets a contiguous super-range of the (pixel tile, channel tile) pairs
+    // persistent ranges: blocks b and b + 8 share an XCD; every XCD gets a contiguous super-range of the (pixel tile, channel tile) pairs and
+    // every workgroup a contiguous piece of it, so the overlapping halos of neighbouring tiles and the re-read of a pixel tile by its
+    // channel tiles are served by that XCD's L2
     const int b = blockIdx.x;
     const int bp = (b & 7) * (G >> 3) + (b >> 3);
     const long long P = (long long)nMt * nNt;
@@ -516,8 +519,11 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
         }
     };
 
-    // ---- POOL epilogue (see sepconv_kernels.hip:store_tile_pool for the derivation): MaxPooling2D(3, 2, "same") of the
-    // tile from the accumulators; row 2w + 2 comes from wave w + 1 through the exchange buffer
+    // ---- POOL epilogue: MaxPooling2D(3, 2, "same") of the tile straight from the accumulators (TF pads AFTER: pooled pixel (py, px) covers
+    // rows 2 py .. 2 py + 2).  PIXMAP puts, for every x-quad, tile row 2w in one half wave and row 2w + 1 in the other, so one cross-half
+    // exchange gives a half wave both rows of its 9 columns; row 2w + 2 comes from wave w + 1 through the exchange buffer (already pooled
+    // along x).  Row 7 / column 7 of a tile need row 16 / column 16 of the next tile: they are stored as partial maxima, the tile's own
+    // row 0 / column 0 / corner go to three strips, and pool_fix_add_kernel finishes the 15 boundary pixels per tile in place.
     int tl_s = -1;          // step index for the WS_DIAG timeline stamps inside the epilogue
     auto store_tile_pool = [&](int jj, float *xch) {
 #ifdef WS_DIAG
@@ -862,9 +868,54 @@ bool launch_sepconv_ws_stem(const float *x, int N, int H, int W, int Cin, const 
     return true;
 }
 
-// pool_fix_add_kernel lives in sepconv_kernels.hip; the strips have that kernel's 8-wave (16 x 16 tile) layout
-void launch_pool_fix_add(float *out, const float *sh, const float *sv, const float *co, const float *resid, int N, int H, int W, int Cout, int nw,
-                         hipStream_t s);
+// Finishes the pooling the separable convolution started in its epilogue: the partial pooled values of a tile's last row /
+// column take the missing row / column from the strips of the tile below / to the right (nothing at the patch border: TF pads
+// with -inf) and get their residual, in place.  A tile has PR x 8 pooled pixels (PR = waves per workgroup of the convolution);
+// one thread = 4 channels of one of its 8 + PR - 1 boundary pixels.
+__global__ __launch_bounds__(256) void pool_fix_add_kernel(float *__restrict__ out, const float *__restrict__ strip_h, const float *__restrict__ strip_v,
+                                                           const float *__restrict__ corner, const float *__restrict__ resid, int Hp, int Wp, int C,
+                                                           int c4shift, int total, int PR)
+{
+    const int n = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int cq = e & ((1 << c4shift) - 1);
+    const int bp = e >> c4shift;                     // boundary pixel: tile * NB + k
+    const int NB = 8 + PR - 1;
+    const int tile = bp / NB, k = bp - tile * NB;
+    const int TH = Hp / PR, TW = Wp >> 3, ty = tile / TW, tx = tile - ty * TW;
+    const int pl = k < 8 ? PR - 1 : k - 8, ql = k < 8 ? k : 7;
+    const size_t o = (((size_t)n * Hp + ty * PR + pl) * Wp + tx * 8 + ql) * C + cq * 4;
+    float4 m = *reinterpret_cast<const float4 *>(out + o);
+    auto take = [&](const float *src) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + cq * 4);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+    };
+    const bool below = pl == PR - 1 && ty + 1 < TH, right = ql == 7 && tx + 1 < TW;
+    if (below) take(strip_h + ((((size_t)n * TH + ty + 1) * TW + tx) * 8 + ql) * C);
+    if (right) take(strip_v + ((((size_t)n * TH + ty) * TW + tx + 1) * PR + pl) * C);
+    if (below && right) take(corner + (((size_t)n * TH + ty + 1) * TW + tx + 1) * C);
+    const float4 rv = *reinterpret_cast<const float4 *>(resid + o);
+    m.x = m.x + rv.x; m.y = m.y + rv.y; m.z = m.z + rv.z; m.w = m.w + rv.w;
+    *reinterpret_cast<float4 *>(out + o) = m;
+}
+
+// finishes the tile edges of a pooled separable convolution (tiles of 2 nw rows x 16 columns; Cout / 4 a power of two)
+static void launch_pool_fix_add(float *out, const float *sh, const float *sv, const float *co, const float *resid, int N, int H, int W, int Cout, int nw,
+                         hipStream_t s)
+{
+    int c4shift = 0;
+    while ((1 << c4shift) < Cout / 4) c4shift++;
+    const int total = (H / (2 * nw)) * (W / 16) * (8 + nw - 1) * (Cout / 4);
+    hipLaunchKernelGGL(pool_fix_add_kernel, dim3((total + 255) / 256, N), dim3(256), 0, s, out, sh, sv, co, resid, H / 2, W / 2, Cout, c4shift, total, nw);
+}
+
+// strips of the pooled form: row 0 / column 0 of every tile, already pooled along the row / column, and its corner pixel (8 + 8 + 1 pixels per 16 x 16 tile)
+size_t sepconv_pool_scratch_floats(int N, int H, int W, int Cout)
+{
+    return (size_t)N * (H / 16) * (W / 16) * 17 * Cout;
+}
+
 
 bool launch_sepconv_pool_ws(const float *in, int N, int H, int W, int Cin, int relu_in, const float *dw9, const float *pwk, int Cout,
                             const float *scale, const float *shift, int relu_out, float *scratch, const float *resid, float *out, hipStream_t s, int prec)

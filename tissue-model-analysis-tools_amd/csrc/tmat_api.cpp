@@ -209,16 +209,6 @@ static bool build_model(Ctx *c, const std::map<std::string, Tensor> &m)
                 return false;
             }
             fold_bn(bn, b, sc, sh);
-            {   // [9][C] -> [C/16][9][16]
-                const int C = (int)(dw.count / 9);
-                std::vector<float> q(dw.count);
-                if (C % 16 == 0) {
-                    for (int cb = 0; cb < C / 16; cb++)
-                        for (int tp = 0; tp < 9; tp++)
-                            for (int e = 0; e < 16; e++) q[((size_t)cb * 9 + tp) * 16 + e] = dw.data[(size_t)tp * C + cb * 16 + e];
-                    if (!upload(c, q, &d.dwq[s]) || !upload(c, std::vector<float>(pw.data, pw.data + pw.count), &d.pwT[s])) return false;
-                }
-            }
             if (!upload(c, std::vector<float>(dw.data, dw.data + dw.count), &d.dw[s]) ||
                 !upload_conv(c, k_contiguous(pw.data, 1, pw.shape[0], pw.shape[1]), pw.shape[0], &d.pw[s]) || !upload(c, sc, &d.scale[s]) ||
                 !upload(c, sh, &d.shift[s])) return false;
@@ -316,7 +306,7 @@ static bool down_block_ws(const Ctx *c, size_t bi)
 {
     const DownBlock &d = c->down[bi];
     const int H = (c->patch / 2) >> bi;
-    return c->fused_sep && c->sep_ws && sepconv_ws_supported(H, H, d.cin, d.cout) && sepconv_ws_supported(H, H, d.cout, d.cout) &&
+    return c->fused_sep && sepconv_ws_supported(H, H, d.cin, d.cout) && sepconv_ws_supported(H, H, d.cout, d.cout) &&
            ((d.cout / 4) & (d.cout / 4 - 1)) == 0;
 }
 
@@ -341,7 +331,7 @@ int unet_down_dev(Ctx *c, const float *X, int n, float *dout, hipStream_t s)
         auto &d = c->down[bi];
         // prev = b0 (n, H, H, cin)
         if (down_block_ws(c, bi)) {
-            // wave-specialised fused kernels (sepconv_ws_kernels.hip): depthwise producers + MFMA consumers in one workgroup.
+            // fused separable kernels (sepconv_ws_kernels.hip): depthwise producers + MFMA consumers in one workgroup.
             // bf16x3 mode: the pointwise contraction on the split weights (bf16x6 keeps these layers in f32: three planes do not fit the LDS budget)
             const float *pw0 = d.pw[0], *pw1 = d.pw[1];
             int sprec = 0;
@@ -364,25 +354,6 @@ int unet_down_dev(Ctx *c, const float *X, int n, float *dout, hipStream_t s)
                 if (!launch_sepconv_pool_ws(b2, n, H, H, d.cout, 0, d.dw[1], pw1, d.cout, d.scale[1], d.shift[1], 0, b3, b1, nxt, s, sprec)) return TMAT_E_ARG;
             } else {
                 if (!launch_sepconv_ws(b2, n, H, H, d.cout, 0, d.dw[1], pw1, d.cout, d.scale[1], d.shift[1], 0, b3, s, sprec)) return TMAT_E_ARG;
-                launch_maxpool_add(b3, n, H, H, d.cout, b1, nxt, s);
-            }
-            H /= 2;
-            continue;
-        }
-        if (c->fused_sep && d.dwq[0] && d.dwq[1] && sepconv_supported(H, H, d.cin, d.cout) && sepconv_supported(H, H, d.cout, d.cout)) {
-            // stem output is already >= 0, so ReLU on load is the identity in the first block
-            if (!launch_sepconv(b0, n, H, H, d.cin, bi > 0, d.dwq[0], d.pwT[0], d.cout, d.scale[0], d.shift[0], 1, b2, s)) return TMAT_E_ARG;
-            ConvArgs r{};
-            r.in = b0; r.N = n; r.h = H; r.w = H; r.Cin = d.cin; r.ksize = 1; r.stride = 2; r.W = d.res_w; r.Cout = d.cout;
-            r.scale = nullptr; r.shift = d.res_b; r.out = b1;
-            if (!conv(c, r, s)) return TMAT_E_ARG;
-            float *nxt = bi + 1 == c->down.size() ? dout : b0;
-            if (c->fused_pool && ((d.cout / 4) & (d.cout / 4 - 1)) == 0) {
-                // pooling + residual add behind the second separable convolution: its full-resolution output never reaches HBM
-                // (b3 only holds the tile-edge strips, 17 of a tile's 256 pixels)
-                if (!launch_sepconv_pool(b2, n, H, H, d.cout, 0, d.dwq[1], d.pwT[1], d.cout, d.scale[1], d.shift[1], 0, b3, b1, nxt, s)) return TMAT_E_ARG;
-            } else {
-                if (!launch_sepconv(b2, n, H, H, d.cout, 0, d.dwq[1], d.pwT[1], d.cout, d.scale[1], d.shift[1], 0, b3, s)) return TMAT_E_ARG;
                 launch_maxpool_add(b3, n, H, H, d.cout, b1, nxt, s);
             }
             H /= 2;
@@ -564,7 +535,6 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
     c->max_patches = max_patches > 0 ? max_patches : 400;
     if (const char *e = getenv("TMAT_FUSED_SEP")) c->fused_sep = atoi(e) != 0;
     if (const char *e = getenv("TMAT_FUSED_POOL")) c->fused_pool = atoi(e) != 0;
-    if (const char *e = getenv("TMAT_SEP_WS")) c->sep_ws = atoi(e) != 0;
     if (const char *e = getenv("TMAT_STEM_FUSED")) c->stem_fused = atoi(e) != 0;
     if (const char *e = getenv("TMAT_SEP_BF16")) c->sep_bf16 = atoi(e) != 0;
     const char *prec_env = getenv("TMAT_PRECISION");

@@ -10,9 +10,7 @@ namespace tmat {
 struct DownBlock {
     int cin = 0, cout = 0;
     float *dw[2] = {nullptr, nullptr};      // [9][C]
-    float *dwq[2] = {nullptr, nullptr};     // the same taps as [C/16][9][16] for the fused separable kernel
-    float *pw[2] = {nullptr, nullptr};      // [Cout][Cin] (k contiguous, conv_mfma_kernel)
-    float *pwT[2] = {nullptr, nullptr};     // [Cin][Cout] (fused separable kernel)
+    float *pw[2] = {nullptr, nullptr};      // [Cout][Cin] (k contiguous: conv_mfma_kernel and the fused separable kernel)
     float *scale[2] = {nullptr, nullptr}, *shift[2] = {nullptr, nullptr};
     float *res_w = nullptr, *res_b = nullptr;
 };
@@ -159,10 +157,9 @@ struct Ctx {
     int precision = 0;                                       // TMAT_PRECISION_F32 (bit-exact contract) or TMAT_PRECISION_BF16X3 / _BF16X6 (opt-in, tmat_set_precision)
     std::map<const float *, ConvWHost> conv_w_host;          // device pointer of every MFMA convolution weight tensor -> its host copy
     std::map<int, std::map<const float *, float *>> wsplit;  // precision mode -> (... -> its split-precision copy on the device, made on first use)
-    bool sep_ws = true;                                      // wave-specialised form of the fused separable kernel (TMAT_SEP_WS=0: sepconv_mfma_kernel)
     bool sep_bf16 = true;                                    // bf16x3 mode also runs the separable layers' pointwise part on the bf16 cores (TMAT_SEP_BF16=0: f32)
     bool stem_fused = true;                                  // the stem recomputed inside block 0's first separable convolution (TMAT_STEM_FUSED=0: stem_kernel writes its tensor)
-    bool fused_sep = true;                                   // fused depthwise->pointwise kernel where the level allows (TMAT_FUSED_SEP=0: off)
+    bool fused_sep = true;                                   // fused depthwise -> pointwise kernel (sepconv_ws_kernel) where the level allows (TMAT_FUSED_SEP=0: separate kernels)
     // profiling of the dominant kernel family
     bool prof_on = false;
     std::vector<ProfEv> ev_open;

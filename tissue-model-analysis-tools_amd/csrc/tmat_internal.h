@@ -31,15 +31,10 @@ struct ConvArgs {
 };
 // returns false (and sets the error) on unsupported shapes
 bool launch_conv(const ConvArgs &a, hipStream_t s);
-// fused SeparableConv2D (sepconv_kernels.hip): depthwise taps dwq [Cin/16][9][16], pointwise pwT [Cin][Cout]
-bool sepconv_supported(int H, int W, int Cin, int Cout);
-bool launch_sepconv(const float *in, int N, int H, int W, int Cin, int relu_in, const float *dwq, const float *pw, int Cout,
-                    const float *scale, const float *shift, int relu_out, float *out, hipStream_t s);
-// the same with MaxPooling2D(3, 2, "same") + residual add fused behind it: out (N, H/2, W/2, Cout); scratch: sepconv_pool_scratch_floats
+// strips of the pooled separable convolution (floats): sepconv_ws_kernels.hip
 size_t sepconv_pool_scratch_floats(int N, int H, int W, int Cout);
-bool launch_sepconv_pool(const float *in, int N, int H, int W, int Cin, int relu_in, const float *dwq, const float *pw, int Cout,
-                         const float *scale, const float *shift, int relu_out, float *scratch, const float *resid, float *out, hipStream_t s);
-// wave-specialised form (sepconv_ws_kernels.hip): depthwise taps dw9 [9][Cin], pointwise pwk [Cout][Cin]; same results, same strips
+// fused SeparableConv2D, wave-specialised (sepconv_ws_kernels.hip): depthwise taps dw9 [9][Cin], pointwise pwk [Cout][Cin] (k contiguous);
+// the pooled form fuses MaxPooling2D(3, 2, "same") + the residual add behind it: out (N, H/2, W/2, Cout), scratch: sepconv_pool_scratch_floats
 bool sepconv_ws_supported(int H, int W, int Cin, int Cout);
 bool launch_sepconv_ws(const float *in, int N, int H, int W, int Cin, int relu_in, const float *dw9, const float *pwk, int Cout,
                        const float *scale, const float *shift, int relu_out, float *out, hipStream_t s, int prec = 0);

@@ -32,6 +32,9 @@ def build_hip(force=False, verbose=True) -> Path:
     srcs = sorted(CSRC.glob("*.hip")) + sorted(CSRC.glob("*.cpp"))
     jobs = []
     objs = []
+    for stale in OBJ.glob("*.o"):                 # objects of sources that no longer exist (tools/build_variant.sh links build/*.o)
+        if stale.name[:-2] not in {s.name for s in srcs}:
+            stale.unlink()
     for s in srcs:
         o = OBJ / (s.name + ".o")
         objs.append(o)

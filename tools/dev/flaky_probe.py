@@ -21,4 +21,4 @@ for n in (2, 3):
             if nb:
                 bad.append((it, rep, nb, float(np.abs(y - ex).max())))
         h.close()
-    print("TMAT_SEP_WS", os.environ.get("TMAT_SEP_WS", "1"), "n", n, "iters", iters, "bad", bad, flush=True)
+    print("TMAT_FUSED_SEP", os.environ.get("TMAT_FUSED_SEP", "1"), "n", n, "iters", iters, "bad", bad, flush=True)

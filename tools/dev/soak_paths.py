@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""dev soak (GPU box): the shipped kernels against the unfused / round-2 forms of the same layers, bit for bit, over many random batches --
+"""dev soak (GPU box): the shipped kernels (fused separable layers with the stem recomputed inside, activated block-output copies) against
+the unfused reference forms of the same layers (separate stem / depthwise / pointwise / pooling kernels, ReLU on load), bit for bit, over many random batches --
 two handles in one process (the switches are read when a handle is created).  Catches rare hazards (inline assembly, barriers, LDS aliasing)
 that a single parity test can miss.   python tools/dev/soak_paths.py [iterations] [patches]"""
 import os
@@ -15,9 +16,11 @@ iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 blob = synth.pack_weights(synth.synth_weights(0))
 h_new = _lib.Handle(blob, 0, n)
-os.environ["TMAT_SEP_WS"] = "0"; os.environ["TMAT_FUSED_SEP"] = "0"; os.environ["TMAT_FUSED_POOL"] = "0"
-h_ref = _lib.Handle(blob, 0, n)                      # unfused depthwise + pointwise + pooling kernels
-for k in ("TMAT_SEP_WS", "TMAT_FUSED_SEP", "TMAT_FUSED_POOL"):
+REF = ("TMAT_FUSED_SEP", "TMAT_FUSED_POOL", "TMAT_STEM_FUSED", "TMAT_RELU_COPY")
+for k in REF:
+    os.environ[k] = "0"
+h_ref = _lib.Handle(blob, 0, n)                      # separate stem + depthwise + pointwise + pooling kernels, ReLU on load
+for k in REF:
     del os.environ[k]
 rs = np.random.RandomState(12345)
 bad = 0
