@@ -256,7 +256,7 @@ def main():
     elapsed = time.perf_counter() - t0
     log(f"timed region {elapsed:.2f} s")
     # second figure, outside the contract's timed region: the same step through the host-pointer entry (PCIe inclusive), a few steps
-    n_host_steps = max(1, min(3, args.steps))
+    n_host_steps = max(1, min(2, args.steps))
     barrier()
     t0 = time.perf_counter()
     for _ in range(n_host_steps):
