@@ -45,18 +45,60 @@ __device__ __forceinline__ void load8(const uint16_t *p, unsigned v[8])
     v[4] = b.x & 0xffffu; v[5] = b.x >> 16; v[6] = b.y & 0xffffu; v[7] = b.y >> 16;
 }
 
-__global__ __launch_bounds__(256) void zproj_focus_kernel(const uint16_t *__restrict__ stacks, int Z, int H, int W,
+// Round 4: the input tile is double-buffered and the NEXT slice travels global -> LDS by LDS-DMA (no registers, no ds_write) while the
+// current slice is filtered.  Rounds 1-3 loaded a slice into LDS with 2-byte gathers and waited at a barrier: the counters showed the
+// waves waiting 59 % of their cycles (profiles/r03_zproj_pmc.txt).  Interior tiles (no reflection, even W: every pixel pair of the 72 x 72
+// window is 4 contiguous, aligned bytes) use the DMA: piece j = 256 bytes of the flat tile, 4 bytes per lane, its global offset recomputed
+// per slice from the lane id (6 vector instructions; 11 pieces per wave) so that nothing lives in registers across the filter stages;
+// border tiles keep the reflect-101 gather.  Two separate LDS objects for the two buffers: with one array hipcc cannot tell the DMA
+// target from the ds_read source and waits for the DMA before the first read of the stage it should overlap with.
+typedef __attribute__((address_space(3))) void zp_lds_void_t;
+constexpr int ZIN = ZI * ZI + 64;       // the last DMA piece is written whole (256 bytes): pad the tile to 41 pieces
+
+#ifndef ZP_WPS
+#define ZP_WPS 4        // waves per SIMD the kernel is compiled for (128 registers; 3 values spill)
+#endif
+__global__ __launch_bounds__(256, ZP_WPS) void zproj_focus_kernel(const uint16_t *__restrict__ stacks, int Z, int H, int W,
                                                           uint16_t *__restrict__ out)
 {
-    __shared__ __attribute__((aligned(8))) uint16_t in[ZI][ZI];
+    __shared__ __attribute__((aligned(16))) uint16_t inA[ZIN];
+    __shared__ __attribute__((aligned(16))) uint16_t inB[ZIN];
     __shared__ __attribute__((aligned(8))) uint16_t bl[ZB][ZBS];
     __shared__ int ry[ZI], rx[ZI];
     const int t = threadIdx.x;
+    const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int x0 = blockIdx.x * ZT, y0 = blockIdx.y * ZT;
     const size_t npx = (size_t)H * W;
     const uint16_t *st = stacks + (size_t)blockIdx.z * Z * npx;
     if (t < ZI) { ry[t] = reflect101(y0 - 4 + t, H); rx[t] = reflect101(x0 - 4 + t, W); }
     __syncthreads();
+    // uniform per block: the whole window lies inside the image, pixel pairs are 4-byte aligned, the stack fits a buffer descriptor
+    const bool fast = x0 >= 4 && x0 + ZT + 4 <= W && y0 >= 4 && y0 + ZT + 4 <= H && (W & 1) == 0 &&
+                      (size_t)Z * npx * 2 < 0x7fffffffull && ((reinterpret_cast<uintptr_t>(st) & 3) == 0);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)st, 0, 0x7fffffff, 0x00020000);
+    constexpr int NPIECE = (ZI * ZI * 2 + 255) / 256;                    // 41
+    auto issue_dma = [&](uint16_t *dst, int z) __attribute__((always_inline)) {
+        const int soff = (int)((size_t)z * npx * 2);
+        int lane_o = lane;                                               // opaque: as loop invariants the 11 offsets would live in registers
+        asm volatile("" : "+v"(lane_o));                                 // across both filter stages (156 instead of 128 VGPRs: 3 waves per SIMD)
+#pragma unroll
+        for (int i = 0; i < (NPIECE + 3) / 4; i++) {
+            const int j = wave + 4 * i;                                  // wave-uniform piece index
+            if (j < NPIECE) {
+                const int pix = 128 * j + 2 * lane_o;
+                const int iy = pix / ZI, ix = pix - iy * ZI;
+                const unsigned vo = pix < ZI * ZI ? (unsigned)(((y0 - 4 + iy) * W + x0 - 4 + ix) * 2) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (zp_lds_void_t *)(dst + 128 * j), 4, vo, soff, 0, 0);
+            }
+        }
+    };
+    auto fill_gather = [&](uint16_t *dst, int z) __attribute__((always_inline)) {
+        const uint16_t *sl = st + (size_t)z * npx;
+        for (int e = t; e < ZI * ZI; e += 256) {
+            const int iy = e / ZI, ix = e - iy * ZI;
+            dst[e] = sl[(size_t)ry[iy] * W + rx[ix]];
+        }
+    };
     const int py = t >> 4, px = t & 15;                  // this thread's 4 x 4 output patch
     int best[4][4];
     unsigned val[4][4];
@@ -64,13 +106,10 @@ __global__ __launch_bounds__(256) void zproj_focus_kernel(const uint16_t *__rest
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int c = 0; c < 4; c++) { best[i][c] = -1; val[i][c] = 0; }
-    for (int z = 0; z < Z; z++) {
-        const uint16_t *sl = st + (size_t)z * npx;
-        for (int e = t; e < ZI * ZI; e += 256) {
-            const int iy = e / ZI, ix = e - iy * ZI;
-            in[iy][ix] = sl[(size_t)ry[iy] * W + rx[ix]];
-        }
-        __syncthreads();
+
+    // one slice: `in` holds slice z, `nxt` receives slice z + 1 meanwhile
+    auto slice = [&](const uint16_t *in, uint16_t *nxt, int z) __attribute__((always_inline)) {
+        if (fast && z + 1 < Z) issue_dma(nxt, z + 1);    // in flight under the two filter stages of slice z
         // stage 1: 17 x 17 patches of the blurred tile
         for (int q = t; q < (ZB / 4) * (ZB / 4); q += 256) {
             const int qy = q / (ZB / 4), qx = q - qy * (ZB / 4);
@@ -78,7 +117,7 @@ __global__ __launch_bounds__(256) void zproj_focus_kernel(const uint16_t *__rest
 #pragma unroll
             for (int r = 0; r < 8; r++) {
                 unsigned v[8];
-                load8(&in[4 * qy + r][4 * qx], v);
+                load8(in + (4 * qy + r) * ZI + 4 * qx, v);
 #pragma unroll
                 for (int c = 0; c < 4; c++) hb[r][c] = v[c] + 4u * v[c + 1] + 6u * v[c + 2] + 4u * v[c + 3] + v[c + 4];
             }
@@ -107,7 +146,7 @@ __global__ __launch_bounds__(256) void zproj_focus_kernel(const uint16_t *__rest
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const uint2 cw = *reinterpret_cast<const uint2 *>(&in[4 * py + 4 + i][4 * px + 4]);      // centre input values
+                const uint2 cw = *reinterpret_cast<const uint2 *>(in + (4 * py + 4 + i) * ZI + 4 * px + 4);      // centre input values
                 const unsigned cv[4] = {cw.x & 0xffffu, cw.x >> 16, cw.y & 0xffffu, cw.y >> 16};
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
@@ -117,7 +156,18 @@ __global__ __launch_bounds__(256) void zproj_focus_kernel(const uint16_t *__rest
                 }
             }
         }
-        __syncthreads();
+        // border tiles: the next slice by the reflect-101 gather (nobody reads `nxt`: slice z - 1's readers passed the barrier above)
+        if (!fast && z + 1 < Z) fill_gather(nxt, z + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed ...
+        __syncthreads();                                  // ... and everybody's: bl is free again, the next input tile is complete
+    };
+
+    if (fast) issue_dma(inA, 0); else fill_gather(inA, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int z = 0; z < Z; z += 2) {
+        slice(inA, inB, z);
+        if (z + 1 < Z) slice(inB, inA, z + 1);
     }
 #pragma unroll
     for (int i = 0; i < 4; i++)
