@@ -33,9 +33,18 @@ def main(rnd):
     side = ("ma_round_kernel", "ma_keys_kernel", "ma_dep_kernel", "ma_", "ms_hist_kernel", "ms_scan_kernel", "ms_scatter_kernel", "dmt_keys_kernel",
             "dmt_sort_kernel", "invert_u8", "weight_kernel", "gauss_axis", "zoom_clip", "rescale255", "minmax_kernel")
 
+    # kernels of the tail of a pass (blend, threshold, mask filter, EDT: pipeline.cpp:enqueue_back), on the second stream beside the next
+    # pass's network since round 3: their summed duration includes queueing for CU slots too
+    tail = ("blend_kernel", "binarize_kernel", "threshold_kernel", "median13_kernel", "ccl_", "region_stats_kernel", "zhang_", "skel_fork_kernel",
+            "decide_kernel", "apply_drop_kernel", "edt_", "thin_count")
+
     def stream_of(name):
         base = name.replace("void ", "").split("(")[0].split("<")[0].replace("tmat::", "")
-        return "side (low priority; summed duration = mostly queueing under the next pass's network)" if any(base.startswith(k) for k in side) else "main"
+        if any(base.startswith(k) for k in side):
+            return "side (low priority; summed duration = mostly queueing under the next pass's network)"
+        if any(base.startswith(k) for k in tail):
+            return "second (tail of a pass beside the next pass's network; summed duration includes queueing)"
+        return "main"
     out["top_kernels_by_total_time"] = [
         {"kernel": r["Name"].split("(")[0].replace("void ", ""), "calls": int(r["Calls"]), "total_ms": round(float(r["TotalDurationNs"]) / 1e6, 1),
          "avg_ms": round(float(r["AverageNs"]) / 1e6, 3), "percent": float(r["Percentage"]), "stream": stream_of(r["Name"])} for r in rows[:10]]
