@@ -157,10 +157,22 @@ int tmat_finish_batch(tmat_handle h, const double *pred, const double *dist, con
  * fl_tissue_model_tools.dmtgraph.compute_dmt_graph(img, delta1, delta2) (reference
  * dmtgraph.py:38-99; the contract the un-vendored pydmtgraph C++ extension exposed).
  * img: (rows, cols) f32.  verts: (cap_v, 2) int32 [row, col]; edges: (cap_e, 2) int32.
- * `h` may be NULL (host-only execution of the sequential sweeps).
+ * With a handle the edge keys, the lower-star sort and both persistence sweeps run on its device
+ * (TMAT_DMT_SWEEP_DEVICE=0: the sweeps on the host), `collect` on the host; `h` may be NULL
+ * (host-only execution, sequential sweeps).
  */
 int tmat_dmt_graph(tmat_handle h, const float *img, int rows, int cols, float delta1, float delta2,
                    int32_t *verts, int cap_v, int32_t *edges, int cap_e, int *n_verts, int *n_edges);
+
+/*
+ * The same for n fields of one shape in one call -- the loop over images around compute_dmt_graph
+ * (reference topology.py:148-160 per image, scripts/compute_branches.py:585-594 over images): edge keys,
+ * the lower-star sort and the two persistence sweeps of all fields run as one launch each
+ * (dmtgraph.py:57-93, :277-314), `collect` (dmtgraph.py:317-453) per field on host threads.
+ * imgs: (n, rows, cols) f32.  verts: (n, cap_v, 2) int32, edges: (n, cap_e, 2) int32; n_verts, n_edges: (n).
+ */
+int tmat_dmt_graph_batch(tmat_handle h, const float *imgs, int n, int rows, int cols, float delta1, float delta2,
+                         int32_t *verts, int cap_v, int32_t *edges, int cap_e, int *n_verts, int *n_edges);
 
 /*
  * topology.MorseGraph(img, thresholds, min_branch_length, max_branch_length,

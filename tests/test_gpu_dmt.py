@@ -1,5 +1,6 @@
-"""GPU parity: the device front end of compute_dmt_graph (csrc/dmt_kernels.hip: edge keys + stable lower-star radix sort
-on the device, sweeps + collect on the host) through tmat_dmt_graph(handle, ...), against the goldens that
+"""GPU parity: the device part of compute_dmt_graph (csrc/dmt_kernels.hip: edge keys + stable lower-star radix sort;
+csrc/dmt_sweep_kernels.hip: the two persistence sweeps as levels of data-parallel steps; collect on the host) through
+tmat_dmt_graph(handle, ...) and tmat_dmt_graph_batch, against the goldens that
 tools/make_goldens.py produced by running the reference's dmtgraph.compute_dmt_graph -- all 27 cases, exact vertices and
 edges -- and against the oracle on random fields with heavy ties (ties are where sort stability is the result)."""
 from pathlib import Path
@@ -69,11 +70,52 @@ def test_full_size_field_device_equals_host(plain):
     assert len(V0) > 100 and np.array_equal(V0, V1) and np.array_equal(E0, E1)
 
 
+def test_batches_run_the_sweeps_of_all_fields_in_one_launch(plain):
+    """tmat_dmt_graph_batch: 8 and 16 fields per launch (8 = the pass size of the pipeline: the workgroups of one image then run on
+    one XCD), 3 (they are spread over the XCDs) -- each field's graph equals the one the host-only execution gives, and the two
+    golden fields equal the reference's output."""
+    from tmat_amd import _lib
+    fields = [GD["field_d5"].astype(np.float32), GD["field_m1"].astype(np.float32)] + [synth_field(500 + k, (384, 384)) for k in range(14)]
+    fields[5] = np.zeros((384, 384), np.float32)                          # an empty image inside the batch
+    want = [_lib.dmt_graph(f, 5.0, 10.0) for f in fields]
+    for n in (8, 16, 3):
+        got = _lib.dmt_graph_batch(np.stack(fields[:n]), 5.0, 10.0, handle=plain)
+        for k in range(n):
+            assert np.array_equal(got[k][0], want[k][0]) and np.array_equal(got[k][1], want[k][1]), (n, k)
+    for k, name in enumerate(("d5", "m1")):
+        assert np.array_equal(want[k][0], GD[f"{name}_5.0_10.0_V"].reshape(-1, 2)) and np.array_equal(want[k][1], GD[f"{name}_5.0_10.0_E"].reshape(-1, 2))
+
+
+def test_many_levels_and_ties_in_batches(plain):
+    """Fields built against the level formulation: a staircase whose minima get older to the left while its saddles get lower to the
+    right (the sequential sweep merges right to left, one link per level: > 100 levels), and 8 random fields of six distinct values
+    (long runs of equal keys, dropped edges) -- against the oracle."""
+    from oracle import dmt as odmt
+    from tmat_amd import _lib
+    N = 260
+    c = np.arange(N)
+    row = np.where(c % 2 == 0, 1000.0 - c, 1.0 + c).astype(np.float32)     # img = -val: minima of val at even columns, saddles at odd ones
+    stair = np.stack([row, row + 0.25, row + 0.5])
+    for d in DELTAS:
+        V0, E0 = odmt.compute_dmt_graph(stair, *d)
+        V1, E1 = _lib.dmt_graph(stair, *d, handle=plain)
+        assert np.array_equal(V0, V1) and np.array_equal(E0, E1)
+    rs = np.random.RandomState(77)
+    f = np.round(rs.uniform(0, 5, (8, 70, 83))).astype(np.float32) * 50
+    f[rs.uniform(size=f.shape) < 0.2] = 0.0
+    f[3] = np.stack([np.resize(row, 83)] * 70) + np.arange(70, dtype=np.float32)[:, None] * 0.125
+    for d in DELTAS:
+        got = _lib.dmt_graph_batch(f, *d, handle=plain)
+        for k in range(8):
+            V0, E0 = odmt.compute_dmt_graph(f[k], *d)
+            assert np.array_equal(V0, got[k][0]) and np.array_equal(E0, got[k][1]), (d, k)
+
+
 def test_device_sweeps_match_reference_goldens_and_timing():
-    """TMAT_DMT_SWEEP_DEVICE=1: the two persistence sweeps (dmtgraph.py:277-314) as a one-wave-per-image kernel
-    (csrc/dmt_sweep_kernels.hip), `collect` on the host: all 27 golden cases exact.  Runs in a child process (the switch is
-    read once per process) and prints the time of the 384 x 384 case next to the host sweeps' -- the kernel is NOT the
-    default: it is slower than the host threads it would replace."""
+    """The two persistence sweeps (dmtgraph.py:277-314) on the device as levels of data-parallel steps (csrc/dmt_sweep_kernels.hip,
+    the default) and on host threads (TMAT_DMT_SWEEP_DEVICE=0), `collect` on the host either way: all 27 golden cases exact in
+    both settings.  Runs in child processes (the switch is read when a handle is created) and prints the time of the 384 x 384
+    case for both."""
     import os, subprocess, sys
     code = r'''
 import sys, time

@@ -122,6 +122,12 @@ int dmt_graph_host_sorted(const float *img, int R, int C, float delta1, float de
         int a, b; gd.endpoints(se[i], a, b);
         ea[i] = a; eb[i] = b; ev[i] = val[a] > val[b] ? val[a] : val[b];
     }
+    // the device kernel marks a sweep whose levels stopped making progress -- which the formulation excludes -- with kind[0] = 0xFF:
+    // that is an error, not something to paper over (TMAT_DMT_SWEEP_DEVICE=0 runs the sweeps below instead)
+    if (kind_in && pers_in && m > 0 && kind_in[0] == 0xFF) {
+        set_error("tmat_dmt_graph: the device persistence sweeps made no progress (dmt_sweep_kernels.hip); TMAT_DMT_SWEEP_DEVICE=0 runs them on the host");
+        return TMAT_E_HIP;
+    }
     if (kind_in && pers_in) {
         for (int i = 0; i < m; i++) { kind[i] = kind_in[i]; pers[i] = pers_in[i]; }
     } else {
@@ -248,4 +254,22 @@ extern "C" int tmat_dmt_graph(tmat_handle hd, const float *img, int rows, int co
     if (!hd || rows < 2 || cols < 2)      // no handle: host-only execution (key build and sort included)
         return tmat::dmt_graph_host(img, rows, cols, delta1, delta2, verts, cap_v, edges, cap_e, n_verts, n_edges);
     return tmat::dmt_graph_device_front(hd, img, rows, cols, delta1, delta2, verts, cap_v, edges, cap_e, n_verts, n_edges);
+}
+
+extern "C" int tmat_dmt_graph_batch(tmat_handle hd, const float *imgs, int n, int rows, int cols, float delta1, float delta2, int32_t *verts,
+                                    int cap_v, int32_t *edges, int cap_e, int *n_verts, int *n_edges)
+{
+    if (!imgs || !verts || !edges || !n_verts || !n_edges || n < 0 || cap_v < 0 || cap_e < 0) {
+        tmat::set_error("tmat_dmt_graph_batch: bad argument");
+        return TMAT_E_ARG;
+    }
+    if (n == 0) return TMAT_OK;
+    if (hd && rows >= 2 && cols >= 2)
+        return tmat::dmt_graph_device_batch(hd, imgs, n, rows, cols, delta1, delta2, verts, cap_v, edges, cap_e, n_verts, n_edges);
+    for (int i = 0; i < n; i++) {
+        const int rc = tmat::dmt_graph_host(imgs + (size_t)i * rows * cols, rows, cols, delta1, delta2, verts + (size_t)i * 2 * cap_v, cap_v,
+                                            edges + (size_t)i * 2 * cap_e, cap_e, n_verts + i, n_edges + i);
+        if (rc) return rc;
+    }
+    return TMAT_OK;
 }

@@ -80,6 +80,15 @@ static int ensure_pass_buffers(Ctx *c, int K, int H, int W, int h, int w, int fh
             DALLOC(b.dmt_m[i], (size_t)K * sizeof(int));
             HALLOC(b.dmt_m_host[i], (size_t)K * sizeof(int));
         }
+        if (c->dmt_device && c->dmt_sweep_device) {
+            DALLOC(b.dmt_sweep_ws, dmt_sweep_workspace_bytes(K, fh, fw));
+            for (int i = 0; i < 2; i++) {
+                DALLOC(b.dmt_kind[i], (size_t)K * nE);
+                HALLOC(b.dmt_kind_host[i], (size_t)K * nE);
+                DALLOC(b.dmt_pers[i], (size_t)K * nE * sizeof(float));
+                HALLOC(b.dmt_pers_host[i], (size_t)K * nE * sizeof(float));
+            }
+        }
     }
     b.fh = fh; b.fw = fw;
     for (int i = 0; i < 2; i++) {
@@ -274,6 +283,13 @@ static void run_pass_host(Ctx *c, int slot, int k, const GraphParams gp, tmat_ro
         ok = ok && hipMemcpyAsync(b.dmt_ids_host[slot], b.dmt_ids[slot], k * nE * sizeof(int32_t), hipMemcpyDeviceToHost, s) == hipSuccess;
         ok = ok && hipMemcpyAsync(b.dmt_m_host[slot], b.dmt_m[slot], k * sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess;
     }
+    // ... and the two persistence sweeps (one workgroup per image, one launch): pairing kind + persistence per sorted edge
+    const bool sweep_dev = dmt_dev && b.dmt_sweep_ws;
+    if (sweep_dev) {
+        ok = ok && dmt_sweeps_dev(b.f255[slot], b.dmt_ids[slot], b.dmt_m[slot], k, gp.fh, gp.fw, b.dmt_sweep_ws, b.dmt_kind[slot], b.dmt_pers[slot], s) == 0;
+        ok = ok && hipMemcpyAsync(b.dmt_kind_host[slot], b.dmt_kind[slot], k * nE, hipMemcpyDeviceToHost, s) == hipSuccess;
+        ok = ok && hipMemcpyAsync(b.dmt_pers_host[slot], b.dmt_pers[slot], k * nE * sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess;
+    }
     ok = ok && hipStreamSynchronize(s) == hipSuccess;
     if (!ok) { job->rc = TMAT_E_HIP; return; }
     const double t2 = now_s();
@@ -282,7 +298,8 @@ static void run_pass_host(Ctx *c, int slot, int k, const GraphParams gp, tmat_ro
         std::vector<int32_t> V((size_t)cap_v * 2), E((size_t)cap_e * 2);
         int nv = 0, ne = 0;
         int rc = dmt_graph_host_sorted(b.f255_host[slot] + i * fper, gp.fh, gp.fw, gp.t1, gp.t2, dmt_dev ? b.dmt_ids_host[slot] + i * nE : nullptr,
-                                       dmt_dev ? b.dmt_m_host[slot][i] : 0, V.data(), cap_v, E.data(), cap_e, &nv, &ne);
+                                       dmt_dev ? b.dmt_m_host[slot][i] : 0, V.data(), cap_v, E.data(), cap_e, &nv, &ne,
+                                       sweep_dev ? b.dmt_kind_host[slot] + i * nE : nullptr, sweep_dev ? b.dmt_pers_host[slot] + i * nE : nullptr);
         if (!rc)
             rc = tmat_morse_stats(V.data(), nv, E.data(), ne, gp.fh, gp.fw, gp.smooth, gp.min_len, gp.max_len, gp.remove_isolated, nullptr,
                                   &rows[i].count, &rows[i].total_px, &rows[i].avg_px, nullptr, 0);
@@ -364,40 +381,54 @@ int medial_thin_batch_dev(Ctx *c, const uint8_t *mask_dev, const double *dist_de
     return rc;
 }
 
-// tmat_dmt_graph with a handle: key build + sort on the handle's device, sweeps + collect on the host
-int dmt_graph_device_front(void *handle, const float *img, int R, int C, float delta1, float delta2, int32_t *verts, int cap_v,
+// tmat_dmt_graph / tmat_dmt_graph_batch with a handle: key build + sort + the two persistence sweeps of all n fields on the handle's
+// device (one launch each), `collect` per field on host threads.  Outputs of field i start at verts + 2 i cap_v / edges + 2 i cap_e.
+int dmt_graph_device_batch(void *handle, const float *imgs, int n, int R, int C, float delta1, float delta2, int32_t *verts, int cap_v,
                            int32_t *edges, int cap_e, int *n_verts, int *n_edges)
 {
     Ctx *c = (Ctx *)handle;
     TMAT_HIP(hipSetDevice(c->device));
     const size_t nE = dmt_edge_count(R, C), npx = (size_t)R * C;
     float *df = nullptr; void *ws = nullptr; int32_t *ids = nullptr; int *m = nullptr;
-    std::vector<int32_t> ids_host(nE);
-    int m_host = 0, rc = TMAT_OK;
-    if (!hip_ok(hipMalloc((void **)&df, npx * sizeof(float)), "hipMalloc") || !hip_ok(hipMalloc(&ws, dmt_workspace_bytes(1, R, C)), "hipMalloc") ||
-        !hip_ok(hipMalloc((void **)&ids, nE * sizeof(int32_t)), "hipMalloc") || !hip_ok(hipMalloc((void **)&m, sizeof(int)), "hipMalloc")) rc = TMAT_E_HIP;
-    if (!rc && !hip_ok(hipMemcpyAsync(df, img, npx * sizeof(float), hipMemcpyHostToDevice, c->stream), "H2D")) rc = TMAT_E_HIP;
-    if (!rc && dmt_sorted_edges_dev(df, 1, R, C, ws, ids, m, c->stream)) { set_error("tmat_dmt_graph: device front end failed"); rc = TMAT_E_HIP; }
-    // opt-in: the two persistence sweeps on the device too (dmt_sweep_kernels.hip, one wave per image); `collect` stays on the host
-    static const bool sweep_dev = [] { const char *e = getenv("TMAT_DMT_SWEEP_DEVICE"); return e && atoi(e) != 0; }();
+    std::vector<int32_t> ids_host((size_t)n * nE);
+    std::vector<int> m_host(n, 0);
+    int rc = TMAT_OK;
+    if (!hip_ok(hipMalloc((void **)&df, n * npx * sizeof(float)), "hipMalloc") || !hip_ok(hipMalloc(&ws, dmt_workspace_bytes(n, R, C)), "hipMalloc") ||
+        !hip_ok(hipMalloc((void **)&ids, n * nE * sizeof(int32_t)), "hipMalloc") || !hip_ok(hipMalloc((void **)&m, n * sizeof(int)), "hipMalloc")) rc = TMAT_E_HIP;
+    if (!rc && !hip_ok(hipMemcpyAsync(df, imgs, n * npx * sizeof(float), hipMemcpyHostToDevice, c->stream), "H2D")) rc = TMAT_E_HIP;
+    if (!rc && dmt_sorted_edges_dev(df, n, R, C, ws, ids, m, c->stream)) { set_error("tmat_dmt_graph: device front end failed"); rc = TMAT_E_HIP; }
+    // the two persistence sweeps on the device too (dmt_sweep_kernels.hip; TMAT_DMT_SWEEP_DEVICE=0: on the host); `collect` stays on the host
+    const bool sweep_dev = c->dmt_sweep_device;
     std::vector<uint8_t> kind_host;
     std::vector<float> pers_host;
     void *sws = nullptr; uint8_t *dkind = nullptr; float *dpers = nullptr;
     if (!rc && sweep_dev) {
-        kind_host.resize(nE); pers_host.resize(nE);
-        if (!hip_ok(hipMalloc(&sws, dmt_sweep_workspace_bytes(1, R, C)), "hipMalloc") || !hip_ok(hipMalloc((void **)&dkind, nE), "hipMalloc") ||
-            !hip_ok(hipMalloc((void **)&dpers, nE * sizeof(float)), "hipMalloc")) rc = TMAT_E_HIP;
-        if (!rc && dmt_sweeps_dev(df, ids, m, 1, R, C, sws, dkind, dpers, c->stream)) { set_error("tmat_dmt_graph: device sweeps failed"); rc = TMAT_E_HIP; }
-        if (!rc && (!hip_ok(hipMemcpyAsync(kind_host.data(), dkind, nE, hipMemcpyDeviceToHost, c->stream), "D2H") ||
-                    !hip_ok(hipMemcpyAsync(pers_host.data(), dpers, nE * sizeof(float), hipMemcpyDeviceToHost, c->stream), "D2H"))) rc = TMAT_E_HIP;
+        kind_host.resize((size_t)n * nE); pers_host.resize((size_t)n * nE);
+        if (!hip_ok(hipMalloc(&sws, dmt_sweep_workspace_bytes(n, R, C)), "hipMalloc") || !hip_ok(hipMalloc((void **)&dkind, n * nE), "hipMalloc") ||
+            !hip_ok(hipMalloc((void **)&dpers, n * nE * sizeof(float)), "hipMalloc")) rc = TMAT_E_HIP;
+        if (!rc && dmt_sweeps_dev(df, ids, m, n, R, C, sws, dkind, dpers, c->stream)) { set_error("tmat_dmt_graph: device sweeps failed"); rc = TMAT_E_HIP; }
+        if (!rc && (!hip_ok(hipMemcpyAsync(kind_host.data(), dkind, n * nE, hipMemcpyDeviceToHost, c->stream), "D2H") ||
+                    !hip_ok(hipMemcpyAsync(pers_host.data(), dpers, n * nE * sizeof(float), hipMemcpyDeviceToHost, c->stream), "D2H"))) rc = TMAT_E_HIP;
     }
-    if (!rc && (!hip_ok(hipMemcpyAsync(ids_host.data(), ids, nE * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream), "D2H") ||
-                !hip_ok(hipMemcpyAsync(&m_host, m, sizeof(int), hipMemcpyDeviceToHost, c->stream), "D2H"))) rc = TMAT_E_HIP;
+    if (!rc && (!hip_ok(hipMemcpyAsync(ids_host.data(), ids, n * nE * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream), "D2H") ||
+                !hip_ok(hipMemcpyAsync(m_host.data(), m, n * sizeof(int), hipMemcpyDeviceToHost, c->stream), "D2H"))) rc = TMAT_E_HIP;
     if (!hip_ok(hipStreamSynchronize(c->stream), "sync") && !rc) rc = TMAT_E_HIP;
     hipFree(df); hipFree(ws); hipFree(ids); hipFree(m); hipFree(sws); hipFree(dkind); hipFree(dpers);
     if (rc) return rc;
-    return dmt_graph_host_sorted(img, R, C, delta1, delta2, ids_host.data(), m_host, verts, cap_v, edges, cap_e, n_verts, n_edges,
-                                 sweep_dev ? kind_host.data() : nullptr, sweep_dev ? pers_host.data() : nullptr);
+    std::vector<int> rcs(n, TMAT_OK);
+    parallel_images(n, [&](int i) {
+        rcs[i] = dmt_graph_host_sorted(imgs + i * npx, R, C, delta1, delta2, ids_host.data() + i * nE, m_host[i], verts + (size_t)i * 2 * cap_v, cap_v,
+                                       edges + (size_t)i * 2 * cap_e, cap_e, n_verts + i, n_edges + i, sweep_dev ? kind_host.data() + i * nE : nullptr,
+                                       sweep_dev ? pers_host.data() + i * nE : nullptr);
+    });
+    for (int i = 0; i < n; i++) if (rcs[i]) return rcs[i];
+    return TMAT_OK;
+}
+
+int dmt_graph_device_front(void *handle, const float *img, int R, int C, float delta1, float delta2, int32_t *verts, int cap_v,
+                           int32_t *edges, int cap_e, int *n_verts, int *n_edges)
+{
+    return dmt_graph_device_batch(handle, img, 1, R, C, delta1, delta2, verts, cap_v, edges, cap_e, n_verts, n_edges);
 }
 
 }  // namespace tmat

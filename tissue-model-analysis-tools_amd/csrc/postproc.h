@@ -25,7 +25,10 @@ int dmt_graph_host(const float *img, int R, int C, float delta1, float delta2, i
 int dmt_graph_host_sorted(const float *img, int R, int C, float delta1, float delta2, const int32_t *sorted, int m, int32_t *verts,
                           int cap_v, int32_t *edges, int cap_e, int *n_verts, int *n_edges,
                           const uint8_t *kind_in = nullptr, const float *pers_in = nullptr);
-// with a handle: key build + lower-star sort on its device (csrc/dmt_kernels.hip), sweeps and collect on the host (pipeline.cpp)
+// with a handle: key build + lower-star sort + the persistence sweeps on its device (csrc/dmt_kernels.hip, dmt_sweep_kernels.hip),
+// collect on the host (pipeline.cpp)
+int dmt_graph_device_batch(void *handle, const float *imgs, int n, int R, int C, float delta1, float delta2, int32_t *verts, int cap_v,
+                           int32_t *edges, int cap_e, int *n_verts, int *n_edges);
 int dmt_graph_device_front(void *handle, const float *img, int R, int C, float delta1, float delta2, int32_t *verts, int cap_v,
                            int32_t *edges, int cap_e, int *n_verts, int *n_edges);
 }  // namespace tmat

@@ -413,10 +413,19 @@ __global__ __launch_bounds__(768, 3) void sepconv_ws_kernel(WsArgs a, int nMt, i
         int cc = 0;
         for (int s = 0; s < total; s++) {
             WS_TL(0)
+#ifdef WS_VAR_SLEEP
+            __builtin_amdgcn_s_sleep(WS_VAR_SLEEP);
+#endif
+#ifdef WS_VAR_FETCHPRIO
+            __builtin_amdgcn_s_setprio(WS_VAR_FETCHPRIO);
+#endif
             if (s + 1 < total) fetch((s + 1) & 1);
             WS_STAMP(3)
             WS_TL(1)
             WS_BAR()                                         // consumers: MFMAs of step s issued
+#ifdef WS_VAR_FETCHPRIO
+            __builtin_amdgcn_s_setprio(WS_PRODUCER_PRIO);
+#endif
             WS_STAMP(4)
             WS_TL(2)
             if (s + 1 < total) compute((s + 1) & 1);

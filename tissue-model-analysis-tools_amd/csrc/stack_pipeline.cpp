@@ -471,6 +471,20 @@ static int field_stats_dev(Ctx *c, const float *field, int fh, int fw, float t1,
     std::vector<int32_t> ids_host(nE);
     int m_host = 0;
     if (dmt_sorted_edges_dev(f255, 1, fh, fw, dws, ids, m, s)) { set_error("field stats: DMT front end failed"); return TMAT_E_HIP; }
+    // the two persistence sweeps on the device as well (dmt_sweep_kernels.hip; TMAT_DMT_SWEEP_DEVICE=0: inside dmt_graph_host_sorted)
+    std::vector<uint8_t> kind_host;
+    std::vector<float> pers_host;
+    if (c->dmt_sweep_device) {
+        uint8_t *dkind = A.get<uint8_t>(nE);
+        float *dpers = A.get<float>(nE);
+        void *sws = nullptr;
+        if (A.ok && hip_ok(hipMalloc(&sws, dmt_sweep_workspace_bytes(1, fh, fw)), "hipMalloc")) A.ptrs.push_back(sws); else A.ok = false;
+        if (!A.ok) return TMAT_E_HIP;
+        if (dmt_sweeps_dev(f255, ids, m, 1, fh, fw, sws, dkind, dpers, s)) { set_error("field stats: device sweeps failed"); return TMAT_E_HIP; }
+        kind_host.resize(nE); pers_host.resize(nE);
+        TMAT_HIP(hipMemcpyAsync(kind_host.data(), dkind, nE, hipMemcpyDeviceToHost, s));
+        TMAT_HIP(hipMemcpyAsync(pers_host.data(), dpers, nE * sizeof(float), hipMemcpyDeviceToHost, s));
+    }
     TMAT_HIP(hipMemcpyAsync(f255_host.data(), f255, npx * 4, hipMemcpyDeviceToHost, s));
     TMAT_HIP(hipMemcpyAsync(ids_host.data(), ids, nE * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     TMAT_HIP(hipMemcpyAsync(&m_host, m, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -478,7 +492,8 @@ static int field_stats_dev(Ctx *c, const float *field, int fh, int fw, float t1,
     const int cap_v = (int)npx + 4, cap_e = 3 * (int)npx + 4;
     std::vector<int32_t> V((size_t)cap_v * 2), E((size_t)cap_e * 2);
     int nv = 0, ne = 0;
-    int rc = dmt_graph_host_sorted(f255_host.data(), fh, fw, t1, t2, ids_host.data(), m_host, V.data(), cap_v, E.data(), cap_e, &nv, &ne);
+    int rc = dmt_graph_host_sorted(f255_host.data(), fh, fw, t1, t2, ids_host.data(), m_host, V.data(), cap_v, E.data(), cap_e, &nv, &ne,
+                                   kind_host.empty() ? nullptr : kind_host.data(), pers_host.empty() ? nullptr : pers_host.data());
     row->index = index; row->count = 0; row->total_px = 0; row->avg_px = 0;
     if (!rc)
         rc = tmat_morse_stats(V.data(), nv, E.data(), ne, fh, fw, smooth, min_len, max_len, remove_isolated, pruning_mask, &row->count, &row->total_px,

@@ -544,6 +544,7 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
         return TMAT_E_ARG;
     }
     if (const char *e = getenv("TMAT_DMT_DEVICE")) c->dmt_device = atoi(e) != 0;
+    if (const char *e = getenv("TMAT_DMT_SWEEP_DEVICE")) c->dmt_sweep_device = atoi(e) != 0;
     if (const char *e = getenv("TMAT_THIN_DEVICE")) c->thin_device = atoi(e) != 0;
     // the UNet stream gets the highest priority, the side stream of the post-processing stages (thinning rounds, finish,
     // DMT front end: many short launches that only have to be done before the next pass ends) the lowest: they fill the

@@ -62,6 +62,12 @@ struct PassBuf {
     int32_t *dmt_ids_host[2] = {nullptr, nullptr};
     int *dmt_m[2] = {nullptr, nullptr};
     int *dmt_m_host[2] = {nullptr, nullptr};
+    // the two persistence sweeps on the device (dmt_sweep_kernels.hip): pairing kind and persistence of every sorted edge
+    void *dmt_sweep_ws = nullptr;
+    uint8_t *dmt_kind[2] = {nullptr, nullptr};
+    uint8_t *dmt_kind_host[2] = {nullptr, nullptr};
+    float *dmt_pers[2] = {nullptr, nullptr};
+    float *dmt_pers_host[2] = {nullptr, nullptr};
     hipEvent_t done[2] = {nullptr, nullptr};
     std::vector<WsEnt> ws;                                  // every scratch allocation above with its size (not the Lanczos tables: they are constants)
 };
@@ -131,7 +137,8 @@ struct Ctx {
         PassBuf &b = pass;
         void *dev[] = {b.xi, b.yi, b.xc, b.yc, b.tmp, b.x, b.small, b.mn, b.mx, b.pred[0], b.pred[1], b.morph_ws,
                        b.filt[0], b.filt[1], b.dist[0], b.dist[1], b.finish_ws, b.skel[0], b.skel[1], b.field[0], b.field[1],
-                       b.f255[0], b.f255[1], b.dmt_ws, b.dmt_ids[0], b.dmt_ids[1], b.dmt_m[0], b.dmt_m[1], b.thin_ws, b.nfg[0], b.nfg[1], b.tie};
+                       b.f255[0], b.f255[1], b.dmt_ws, b.dmt_ids[0], b.dmt_ids[1], b.dmt_m[0], b.dmt_m[1], b.thin_ws, b.nfg[0], b.nfg[1], b.tie,
+                       b.dmt_sweep_ws, b.dmt_kind[0], b.dmt_kind[1], b.dmt_pers[0], b.dmt_pers[1]};
         for (void *p : dev) if (p) hipFree(p);
         for (int i = 0; i < 2; i++) {
             if (b.pred_host[i]) hipHostFree(b.pred_host[i]);
@@ -142,6 +149,8 @@ struct Ctx {
             if (b.f255_host[i]) hipHostFree(b.f255_host[i]);
             if (b.dmt_ids_host[i]) hipHostFree(b.dmt_ids_host[i]);
             if (b.dmt_m_host[i]) hipHostFree(b.dmt_m_host[i]);
+            if (b.dmt_kind_host[i]) hipHostFree(b.dmt_kind_host[i]);
+            if (b.dmt_pers_host[i]) hipHostFree(b.dmt_pers_host[i]);
             if (b.nfg_host[i]) hipHostFree(b.nfg_host[i]);
             if (b.tie_host[i]) hipHostFree(b.tie_host[i]);
             if (b.done[i]) hipEventDestroy(b.done[i]);
@@ -151,6 +160,7 @@ struct Ctx {
     bool thin_device = true;                                 // ordered medial-axis thinning on the device (TMAT_THIN_DEVICE=0: host threads)
     uint32_t *ma_table = nullptr;                            // its 512-entry decision table, 16 words
     bool dmt_device = true;                                  // DMT key build + lower-star sort on the device (TMAT_DMT_DEVICE=0: host)
+    bool dmt_sweep_device = true;                            // the two persistence sweeps on the device as well (TMAT_DMT_SWEEP_DEVICE=0: host threads)
     bool fused_pool = true;                                  // max-pool + residual add fused behind the second separable convolution (TMAT_FUSED_POOL=0: separate kernel)
     bool norm_on = false;                                    // models.py:636-637 input normalisation in front of the smooth prediction (tmat_set_input_norm)
     float norm_mean = 0.f, norm_std = 1.f;

@@ -82,7 +82,8 @@ int thin_dev(const uint8_t *mask, const double *dist, const uint32_t *tie, const
 inline size_t dmt_edge_count(int R, int C) { return (size_t)(R - 1) * C + (size_t)R * (C - 1) + (size_t)(R - 1) * (C - 1); }
 size_t dmt_workspace_bytes(int n, int R, int C);
 int dmt_sorted_edges_dev(const float *field, int n, int R, int C, void *ws, int32_t *ids, int *m, hipStream_t s);
-// the two persistence sweeps on the device, one wave per image (dmt_sweep_kernels.hip; opt-in, TMAT_DMT_SWEEP_DEVICE=1)
+// the two persistence sweeps on the device as levels of data-parallel steps, one workgroup per image (dmt_sweep_kernels.hip;
+// TMAT_DMT_SWEEP_DEVICE=0 keeps them on host threads)
 size_t dmt_sweep_workspace_bytes(int n, int R, int C);
 int dmt_sweeps_dev(const float *field, const int32_t *ids, const int *m, int n, int R, int C, void *ws, uint8_t *kind, float *pers, hipStream_t s);
 

@@ -56,6 +56,7 @@ def lib():
     L.tmat_zproj_batch.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.tmat_zproj_dev.argtypes = [vp, vp, i, i, i, i, i, vp]
     L.tmat_dmt_graph.argtypes = [vp, vp, i, i, f, f, vp, i, vp, i, C.POINTER(i), C.POINTER(i)]
+    L.tmat_dmt_graph_batch.argtypes = [vp, vp, i, i, i, f, f, vp, i, vp, i, vp, vp]
     L.tmat_morse_stats.argtypes = [vp, i, vp, i, i, i, i, i, i, i, vp, C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                    C.POINTER(C.c_double), vp, i]
     L.tmat_analyze_batch_dev.argtypes = [vp, vp, i, i, i, C.c_double, i, f, f, i, i, i, i, C.c_int64, vp]
@@ -100,7 +101,7 @@ def lib():
 EXPORTS = [
     "tmat_last_error", "tmat_version", "tmat_create", "tmat_create_plain", "tmat_destroy", "tmat_sync", "tmat_set_input_depth", "tmat_unet_predict",
     "tmat_predict_smooth", "tmat_segment_batch", "tmat_postprocess_batch", "tmat_filter_edt_batch", "tmat_medial_axis_batch", "tmat_finish_batch", "tmat_filter_mask_batch", "tmat_zproj_batch", "tmat_zproj_dev", "tmat_gather_rows",
-    "tmat_dmt_graph", "tmat_morse_stats",
+    "tmat_dmt_graph", "tmat_dmt_graph_batch", "tmat_morse_stats",
     "tmat_analyze_batch_dev", "tmat_analyze_batch", "tmat_dev_alloc", "tmat_dev_free", "tmat_dev_upload",
     "tmat_prof_enable", "tmat_prof_read", "tmat_debug_poison", "tmat_set_precision", "tmat_set_input_norm", "tmat_preprocess_batch", "tmat_well_threshold", "tmat_well_threshold_f64", "tmat_canny_mask", "tmat_host_lanczos4_u16", "tmat_host_rescale01_u16",
     "tmat_host_rescale255_f32", "tmat_host_filter_mask", "tmat_host_skeletonize", "tmat_host_medial_axis",
@@ -262,6 +263,19 @@ def dmt_graph(img: np.ndarray, delta1: float, delta2: float = 0.0, handle: "Hand
     check(lib().tmat_dmt_graph(handle.raw if handle else None, ptr(img), R, Cc, float(delta1), float(delta2), ptr(V), cap_v,
                                ptr(E), cap_e, C.byref(nv), C.byref(ne)), "tmat_dmt_graph")
     return V[: nv.value].copy(), E[: ne.value].copy()
+
+
+def dmt_graph_batch(imgs: np.ndarray, delta1: float, delta2: float = 0.0, handle: "Handle | None" = None):
+    """tmat_dmt_graph_batch: n fields of one shape in one call -> list of (vertices, edges) as dmt_graph returns them."""
+    imgs = np.ascontiguousarray(imgs, np.float32)
+    n, R, Cc = imgs.shape
+    cap_v, cap_e = R * Cc + 4, 3 * R * Cc + 4
+    V = np.empty((n, cap_v, 2), np.int32)
+    E = np.empty((n, cap_e, 2), np.int32)
+    nv, ne = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    check(lib().tmat_dmt_graph_batch(handle.raw if handle else None, ptr(imgs), n, R, Cc, float(delta1), float(delta2), ptr(V), cap_v,
+                                     ptr(E), cap_e, ptr(nv), ptr(ne)), "tmat_dmt_graph_batch")
+    return [(V[k, : nv[k]].copy(), E[k, : ne[k]].copy()) for k in range(n)]
 
 
 def morse_stats(V, E, shape, smoothing_window, min_branch_length, max_branch_length=None,
