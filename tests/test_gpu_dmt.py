@@ -109,6 +109,13 @@ def test_many_levels_and_ties_in_batches(plain):
         for k in range(8):
             V0, E0 = odmt.compute_dmt_graph(f[k], *d)
             assert np.array_equal(V0, got[k][0]) and np.array_equal(E0, got[k][1]), (d, k)
+    # more fields than one launch of the sweep kernel takes (32): the call splits them
+    f = np.round(rs.uniform(0, 9, (70, 21, 34))).astype(np.float32) * 25
+    f[rs.uniform(size=f.shape) < 0.15] = 0.0
+    got = _lib.dmt_graph_batch(f, 2.0, 4.0, handle=plain)
+    for k in range(70):
+        V0, E0 = odmt.compute_dmt_graph(f[k], 2.0, 4.0)
+        assert np.array_equal(V0, got[k][0]) and np.array_equal(E0, got[k][1]), k
 
 
 def test_device_sweeps_match_reference_goldens_and_timing():

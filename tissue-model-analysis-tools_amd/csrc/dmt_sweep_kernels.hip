@@ -25,8 +25,8 @@
 //
 // LV_WG workgroups of LV_THREADS threads per image run both sweeps in ONE launch per pass (on the lowest-priority stream every
 // launch waits for free CUs): the phases of a level are separated by a barrier across the image's workgroups -- a monotonic
-// arrival counter in memory (the shared state is kept coherent by the accesses themselves, see below).  The grid is 8 x LV_WG workgroups
-// of 8 waves, far below what the chip holds at once, and a workgroup waits for nothing but the arrival of its image's other
+// arrival counter in memory (how the shared state is kept coherent: see below).  A launch has at most 32 x LV_WG workgroups
+// of 8 waves, an eighth of what the chip holds at once, and a workgroup waits for nothing but the arrival of its image's other
 // workgroups, which need no resource a waiting workgroup holds: every wave reaches the exit.
 // The parent arrays (147 456 vertices, 293 379 triangles at 384 x 384), the first[] array and the alive lists live in HBM / L2.
 #include "tmat_internal.h"
@@ -289,10 +289,17 @@ int dmt_sweeps_dev(const float *field, const int32_t *ids, const int *m, int n, 
     LvItem *lists = (LvItem *)(first + (size_t)n * nN);
     unsigned *ctl = (unsigned *)(lists + (size_t)n * 2 * nE);
     const int blocks = (int)((nT1 + 255) / 256);
-    // (the images of a launch are independent: a pass of more than 32 images would still be correct, its later images just start
-    // when earlier ones have left -- no workgroup waits for one of another image)
     hipLaunchKernelGGL(dmt_prep_kernel, dim3(blocks < 512 ? blocks : 512, n), dim3(256), 0, s, field, R, C, val, tv, ctl);
-    hipLaunchKernelGGL(dmt_levels_kernel, dim3(n, LV_WG), dim3(LV_THREADS), 0, s, ids, m, nE, R, C, val, tv, par, first, lists, ctl, kind, pers);
+    // At most LV_CHUNK images per launch: the workgroups of an image wait for each other, so all LV_WG x images of a launch must be able
+    // to be resident at once (workgroups are dispatched wg 0 of every image first: with more images than the chip has room for, the
+    // first workgroups would fill it and wait for partners that can never start).  32 x 8 workgroups of 8 waves are an eighth of it.
+    constexpr int LV_CHUNK = 32;
+    for (int i0 = 0; i0 < n; i0 += LV_CHUNK) {
+        const int k = n - i0 < LV_CHUNK ? n - i0 : LV_CHUNK;
+        hipLaunchKernelGGL(dmt_levels_kernel, dim3(k, LV_WG), dim3(LV_THREADS), 0, s, ids + (size_t)i0 * nE, m + i0, nE, R, C, val + (size_t)i0 * nV,
+                           tv + (size_t)i0 * nT1, par + (size_t)i0 * nN, first + (size_t)i0 * nN, lists + (size_t)i0 * 2 * nE, ctl + (size_t)i0 * 4,
+                           kind + (size_t)i0 * nE, pers + (size_t)i0 * nE);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

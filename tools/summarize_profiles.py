@@ -30,7 +30,7 @@ def main(rnd):
     rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
     # kernels of the low-priority side stream (ordered thinning, finish stage, DMT front end: pipeline.cpp:run_pass_host): they run
     # under the next pass's network, so their SUMMED duration is mostly time spent waiting for CU slots, not work
-    side = ("ma_round_kernel", "ma_keys_kernel", "ma_dep_kernel", "ma_", "ms_hist_kernel", "ms_scan_kernel", "ms_scatter_kernel", "dmt_keys_kernel",
+    side = ("ma_round_kernel", "ma_keys_kernel", "ma_dep_kernel", "ma_", "ms_hist_kernel", "ms_scan_kernel", "ms_scatter_kernel", "dmt_keys_kernel", "dmt_levels_kernel", "dmt_prep_kernel",
             "dmt_sort_kernel", "invert_u8", "weight_kernel", "gauss_axis", "zoom_clip", "rescale255", "minmax_kernel")
 
     # kernels of the tail of a pass (blend, threshold, mask filter, EDT: pipeline.cpp:enqueue_back), on the second stream beside the next
