@@ -146,29 +146,49 @@ static bool tail_on_side_stream()
     static const bool side = [] { const char *e = getenv("TMAT_TAIL_STREAM"); return !(e && atoi(e) == 0); }() && use_one_stream();
     return side;
 }
-static int enqueue_front(Ctx *c, const uint16_t *imgs_dev, int k, int slot, const TileGeom &g)
+// The front end of a pass (Lanczos, rescale, tile gather: ~2 ms of memory-bound kernels) runs on the SECOND stream, ahead of time: the
+// one of pass p + 2 is queued when pass p's tail has finished, beside pass p + 1's network, into the input buffer pass p has released
+// (patch_in / patch_in2 alternate), so that on the main stream one pass's network follows the other's directly (TMAT_PRE_STREAM=0 keeps
+// it on the main stream in front of its down path).  An image that needs more patches than the activation workspace holds takes the
+// old route: everything on the main stream, one input buffer.
+static bool pre_on_side_stream(const Ctx *c, const TileGeom &g) { return c->pre_side && tail_on_side_stream() && g.tiles_per_img <= c->max_patches && c->patch_in2; }
+static float *patch_in_of(Ctx *c, int slot, const TileGeom &g) { return pre_on_side_stream(c, g) && (slot & 1) ? c->patch_in2 : c->patch_in; }
+static int enqueue_pre(Ctx *c, const uint16_t *imgs_dev, int k, int slot, const TileGeom &g)
 {
     PassBuf &b = c->pass;
-    // Default: both halves on the main stream.  TMAT_STREAMS=2 puts this half on the second stream; measured +1.8 %
+    const bool oversize = g.tiles_per_img > c->max_patches;
+    const bool side = pre_on_side_stream(c, g);
+    hipStream_t s = side ? c->stream2 : (use_one_stream() || oversize) ? c->stream : c->stream2;
+    // the down path of the pass before last read this buffer (long finished: its whole pass has ended; stated for the record)
+    if (side && c->down_pending[slot]) TMAT_HIP(hipStreamWaitEvent(s, c->ev_down[slot], 0));
+    launch_lanczos(imgs_dev, k, b.H, b.W, b.h, b.w, b.xi, b.xc, b.yi, b.yc, b.tmp, b.small, c->input_sat, s);
+    launch_rescale01(b.small, k, (size_t)b.h * b.w, b.mn, b.mx, b.x, s);
+    if (c->norm_on) launch_norm_f32(b.x, (size_t)k * b.h * b.w, c->norm_mean, c->norm_std, s);      // models.py:636-637
+    float *mn = (float *)c->scratch, *mx = mn + k;
+    launch_minmax_f32(b.x, k, (size_t)b.h * b.w, mn, mx, s);
+    launch_extract_tiles(b.x, mn, k, g, patch_in_of(c, slot, g), s);
+    if (side) TMAT_HIP(hipEventRecord(c->ev_pre[slot], s));
+    return TMAT_OK;
+}
+static int enqueue_down(Ctx *c, int k, int slot, const TileGeom &g)
+{
+    // Default: the network on the main stream.  TMAT_STREAMS=2 puts the front end and the down path on the second stream; measured +1.8 %
     // images/s, but every kernel of the MFMA half then shares the CUs with a memory-bound one and its own duration
     // (the roofline measurement) stretches by 20 %, so the overlap is opt-in.
     // an image that needs more patches than the activation workspace holds: the whole network runs here, chunk by
     // chunk, on the main stream (enqueue_back then only blends)
     const bool oversize = g.tiles_per_img > c->max_patches;
     hipStream_t s = (use_one_stream() || oversize) ? c->stream : c->stream2;
-    launch_lanczos(imgs_dev, k, b.H, b.W, b.h, b.w, b.xi, b.xc, b.yi, b.yc, b.tmp, b.small, c->input_sat, s);
-    launch_rescale01(b.small, k, (size_t)b.h * b.w, b.mn, b.mx, b.x, s);
-    if (c->norm_on) launch_norm_f32(b.x, (size_t)k * b.h * b.w, c->norm_mean, c->norm_std, s);      // models.py:636-637
-    float *mn = (float *)c->scratch, *mx = mn + k;
-    launch_minmax_f32(b.x, k, (size_t)b.h * b.w, mn, mx, s);
-    launch_extract_tiles(b.x, mn, k, g, c->patch_in, s);
+    if (pre_on_side_stream(c, g)) TMAT_HIP(hipStreamWaitEvent(s, c->ev_pre[slot], 0));
     // oversize: the whole network runs HERE and writes the single patch_out, which the blend of the previous pass may still be
     // reading on the second stream (enqueue_back's own wait on ev_blend comes too late: it is issued after this forward)
     if (oversize && tail_on_side_stream() && c->blend_pending[slot ^ 1]) TMAT_HIP(hipStreamWaitEvent(s, c->ev_blend[slot ^ 1], 0));
-    int rc = oversize ? unet_forward_dev(c, c->patch_in, k * g.tiles_per_img, c->patch_out, s)
-                      : unet_down_dev(c, c->patch_in, k * g.tiles_per_img, c->dout[slot], s);
+    float *pin = patch_in_of(c, slot, g);
+    int rc = oversize ? unet_forward_dev(c, pin, k * g.tiles_per_img, c->patch_out, s)
+                      : unet_down_dev(c, pin, k * g.tiles_per_img, c->dout[slot], s);
     if (rc) return rc;
     TMAT_HIP(hipEventRecord(c->ev_down[slot], s));
+    c->down_pending[slot] = true;
     return TMAT_OK;
 }
 static int enqueue_back(Ctx *c, int k, int slot, const TileGeom &g)
@@ -334,9 +354,21 @@ static int analyze_dev(Ctx *c, const uint16_t *imgs_dev, int n, int H, int W, do
     auto img_at = [&](int p) { return imgs_dev + (size_t)p * K * H * W; };
     // the caller may have queued work that produces the images on the main stream (tmat_zproj_dev, tmat_dev_upload)
     if (!use_one_stream() && !hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize")) return TMAT_E_HIP;
-    rc = enqueue_front(c, img_at(0), cnt(0), 0, g);
+    // second input buffer for the front end that runs ahead on the second stream (enqueue_pre)
+    if (c->pre_side && tail_on_side_stream() && g.tiles_per_img <= c->max_patches && !c->patch_in2)
+        TMAT_HIP(hipMalloc((void **)&c->patch_in2, (size_t)c->patch * c->patch * c->patch_cap * sizeof(float)));
+    if (pre_on_side_stream(c, g)) {         // what the caller queued on the main stream (the images) comes first on the second one too
+        TMAT_HIP(hipEventRecord(c->ev_pre[0], c->stream));
+        TMAT_HIP(hipStreamWaitEvent(c->stream2, c->ev_pre[0], 0));
+    }
+    // (order of the calls = order on the second stream: the front end of pass p + 2 in front of the tail of pass p + 1, which only
+    // starts when that pass's up path has ended)
+    c->down_pending[0] = c->down_pending[1] = false;
+    rc = enqueue_pre(c, img_at(0), cnt(0), 0, g);
+    if (!rc) rc = enqueue_down(c, cnt(0), 0, g);
+    if (!rc && P > 1) rc = enqueue_pre(c, img_at(1), cnt(1), 1, g);
     if (!rc) rc = enqueue_back(c, cnt(0), 0, g);
-    if (!rc && P > 1) rc = enqueue_front(c, img_at(1), cnt(1), 1, g);
+    if (!rc && P > 1) rc = enqueue_down(c, cnt(1), 1, g);
     for (int p = 0; p < P && !rc; p++) {
         const int slot = p & 1;
         const double tw0 = now_s();
@@ -346,8 +378,9 @@ static int analyze_dev(Ctx *c, const uint16_t *imgs_dev, int n, int H, int W, do
         if (trace_on())
             fprintf(stderr, "[tmat] pass %d/%d (%d images): waited %.1f ms for the GPU, %.1f ms for host jobs of the previous pass\n",
                     p + 1, P, cnt(p), (tw1 - tw0) * 1e3, (now_s() - tw1) * 1e3);
+        if (p + 2 < P && !rc) rc = enqueue_pre(c, img_at(p + 2), cnt(p + 2), slot, g);
         if (p + 1 < P && !rc) rc = enqueue_back(c, cnt(p + 1), slot ^ 1, g);
-        if (p + 2 < P && !rc) rc = enqueue_front(c, img_at(p + 2), cnt(p + 2), slot, g);
+        if (p + 2 < P && !rc) rc = enqueue_down(c, cnt(p + 2), slot, g);
         for (int i = 0; i < cnt(p) && !rc; i++)
             if (!c->pass.conv_host[slot][i]) { set_error("analyze: Zhang thinning did not converge within its launch budget"); rc = TMAT_E_HIP; }
         if (!rc) jobs[slot].th = std::thread(run_pass_host, c, slot, cnt(p), gp, rows + (size_t)p * K, &jobs[slot]);

@@ -445,9 +445,11 @@ int ensure_patch_io(Ctx *c, int n_patches)
 {
     if (n_patches <= c->patch_cap) return TMAT_OK;
     TMAT_HIP(hipStreamSynchronize(c->stream));
+    TMAT_HIP(hipStreamSynchronize(c->stream2));
     if (c->patch_in) hipFree(c->patch_in);
+    if (c->patch_in2) hipFree(c->patch_in2);
     if (c->patch_out) hipFree(c->patch_out);
-    c->patch_in = c->patch_out = nullptr;
+    c->patch_in = c->patch_in2 = c->patch_out = nullptr;
     c->patch_cap = 0;
     const size_t bytes = (size_t)c->patch * c->patch * n_patches * sizeof(float);
     TMAT_HIP(hipMalloc((void **)&c->patch_in, bytes));
@@ -545,6 +547,7 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
     }
     if (const char *e = getenv("TMAT_DMT_DEVICE")) c->dmt_device = atoi(e) != 0;
     if (const char *e = getenv("TMAT_DMT_SWEEP_DEVICE")) c->dmt_sweep_device = atoi(e) != 0;
+    if (const char *e = getenv("TMAT_PRE_STREAM")) c->pre_side = atoi(e) != 0;
     if (const char *e = getenv("TMAT_THIN_DEVICE")) c->thin_device = atoi(e) != 0;
     // the UNet stream gets the highest priority, the side stream of the post-processing stages (thinning rounds, finish,
     // DMT front end: many short launches that only have to be done before the next pass ends) the lowest: they fill the
@@ -595,6 +598,7 @@ int tmat_create(int device_id, const void *weights_blob, size_t n_bytes, int max
     for (int i = 0; i < 2; i++)
         if (!hip_ok(hipEventCreateWithFlags(&c->ev_down[i], hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&c->ev_pre[i], hipEventDisableTiming), "hipEventCreate") ||
             !hip_ok(hipEventCreateWithFlags(&c->ev_blend[i], hipEventDisableTiming), "hipEventCreate")) { tmat_destroy((tmat_handle)c); return TMAT_E_HIP; }
     const size_t pp = (size_t)patch * patch * c->max_patches * sizeof(float);
     c->scratch_bytes = 64 << 20;
@@ -647,10 +651,11 @@ void tmat_destroy(tmat_handle h)
     for (int i = 0; i < 4; i++) if (c->buf[i]) hipFree(c->buf[i]);
     for (int i = 0; i < 4; i++) if (c->ubuf[i]) hipFree(c->ubuf[i]);
     for (int i = 0; i < 2; i++) { if (c->dout_relu[i]) hipFree(c->dout_relu[i]); if (c->urelu[i]) hipFree(c->urelu[i]); }
-    for (int i = 0; i < 2; i++) { if (c->dout[i]) hipFree(c->dout[i]); if (c->ev_down[i]) hipEventDestroy(c->ev_down[i]); if (c->ev_up[i]) hipEventDestroy(c->ev_up[i]); if (c->ev_blend[i]) hipEventDestroy(c->ev_blend[i]); }
+    for (int i = 0; i < 2; i++) { if (c->dout[i]) hipFree(c->dout[i]); if (c->ev_down[i]) hipEventDestroy(c->ev_down[i]); if (c->ev_up[i]) hipEventDestroy(c->ev_up[i]); if (c->ev_pre[i]) hipEventDestroy(c->ev_pre[i]); if (c->ev_blend[i]) hipEventDestroy(c->ev_blend[i]); }
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->stream3) { hipStreamSynchronize(c->stream3); hipStreamDestroy(c->stream3); }
     if (c->patch_in) hipFree(c->patch_in);
+    if (c->patch_in2) hipFree(c->patch_in2);
     if (c->patch_out) hipFree(c->patch_out);
     if (c->scratch) hipFree(c->scratch);
     if (c->win1d) hipFree(c->win1d);
@@ -800,6 +805,7 @@ int tmat_debug_poison(tmat_handle h, int byte_pattern)
     for (int i = 0; i < 2; i++) { if (c->dout_relu[i]) all.push_back({c->dout_relu[i], c->dout_bytes, false}); if (c->urelu[i]) all.push_back({c->urelu[i], c->urelu_bytes[i], false}); }
     const size_t pio = (size_t)c->patch * c->patch * c->patch_cap * sizeof(float);
     if (c->patch_in) all.push_back({c->patch_in, pio, false});
+    if (c->patch_in2) all.push_back({c->patch_in2, pio, false});
     if (c->patch_out) all.push_back({c->patch_out, pio, false});
     if (c->scratch) all.push_back({c->scratch, c->scratch_bytes, false});
     all.insert(all.end(), c->pass.ws.begin(), c->pass.ws.end());

@@ -121,9 +121,13 @@ struct Ctx {
     hipStream_t stream2 = nullptr;                           // second stream: down path of pass p+1 overlaps up path of pass p
     hipStream_t stream3 = nullptr;                           // third stream: finish stage of pass p-1 (after the host thinning)
     hipEvent_t ev_down[2] = {nullptr, nullptr};
+    hipEvent_t ev_pre[2] = {nullptr, nullptr};              // front end of a pass (Lanczos ... tile gather) done: patch_in_of(slot) is complete
+    bool down_pending[2] = {false, false};
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_blend[2] = {nullptr, nullptr};      // the tail of a pass (blend, mask filter, EDT) on the second stream
     bool blend_pending[2] = {false, false};
     float *patch_in = nullptr, *patch_out = nullptr;
+    float *patch_in2 = nullptr;                              // second input buffer of the batch path: the front end of pass p + 2 runs beside pass p + 1's network (pipeline.cpp)
+    bool pre_side = true;                                    // that front end on the second stream (TMAT_PRE_STREAM=0: on the main stream)
     size_t buf_bytes[4] = {0, 0, 0, 0}, ubuf_bytes[4] = {0, 0, 0, 0}, dout_bytes = 0;      // sizes of the activation workspaces (tmat_debug_poison)
     float input_sat = 65535.f;                               // Lanczos saturation: 65535, or 255 for 8-bit sources (tmat_set_input_depth)
     int patch_cap = 0;                                       // patches patch_in / patch_out hold (>= max_patches)
