@@ -11,6 +11,7 @@
 // Results are identical to csrc/postproc.cpp (host twin used by the stage-wise C-ABI entry points) and to
 // oracle/morph.py: the label ids differ (root pixel index instead of raster rank) but no output depends on them.
 #include "tmat_internal.h"
+#include "dev_guard.h"
 #include "morph.h"
 
 namespace tmat {
@@ -175,11 +176,36 @@ __global__ void region_stats_kernel(const int *__restrict__ L, int H, int W, int
 // reaches the inner tile).  changed[launch][img] is raised when an inner-tile pixel is removed; a launch that removes
 // nothing leaves out == in, so every later launch of that image can return immediately (both buffers hold the result).
 constexpr int ZH_IT = 4, ZH_R = 2 * ZH_IT, ZH_TI = 48, ZH_T = ZH_TI + 2 * ZH_R;     // 64 x 64 staged pixels
+//
+// Tiles (round 4): tflags[launch % 3][img][tile] is raised with it for the TILE.  A tile whose 3 x 3 tile neighbourhood removed nothing
+// in the previous launch has nothing to do in this one: a 144 x 144 region around it stood still through 4 full iterations (so its
+// last iteration was a fixed point there), and what changed further out is >= 40 pixels from the tile's staged area while a launch
+// moves information 8 pixels.  The tile itself did not change in that launch either, so both buffers already hold its pixels and
+// skipping the write is exact.  It wakes up again as soon as a neighbour removes something.  (The slot of the next launch is
+// cleared here: nobody reads it during this launch.)
 __global__ __launch_bounds__(256) void zhang_tile_kernel(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int H, int W,
-                                                         int tiles_x, const int *__restrict__ prev_changed, int *__restrict__ changed)
+                                                         int tiles_x, const int *__restrict__ prev_changed, int *__restrict__ changed,
+                                                         int *__restrict__ tflags, int it)
 {
-    const int img = blockIdx.y;
+    const int img = blockIdx.y, ntiles = gridDim.x, k = gridDim.y;
+    int *tf_w = tflags + ((size_t)(it % 3) * k + img) * ntiles;
+    const int *tf_r = tflags + ((size_t)((it + 2) % 3) * k + img) * ntiles;
+    if (threadIdx.x == 0) tflags[((size_t)((it + 1) % 3) * k + img) * ntiles + blockIdx.x] = 0;
     if (prev_changed && !prev_changed[img]) return;          // converged in an earlier launch
+    if (it > 0) {
+        const int tiles_y = ntiles / tiles_x, ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+#ifdef ZH_VAR_NOSKIP
+        int act = 1;
+#else
+        int act = 0;
+#endif
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                const int yy = ty + dy, xx = tx + dx;
+                if (yy >= 0 && yy < tiles_y && xx >= 0 && xx < tiles_x) act |= tf_r[yy * tiles_x + xx];
+            }
+        if (!act) return;
+    }
     __shared__ uint8_t buf[2][ZH_T * ZH_T];
     const size_t base = (size_t)img * H * W;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
@@ -220,7 +246,7 @@ __global__ __launch_bounds__(256) void zhang_tile_kernel(const uint8_t *__restri
         const int y = y0 + ZH_R + ly, x = x0 + ZH_R + lx;
         if (y < H && x < W) out[base + (size_t)y * W + x] = buf[cur][(ly + ZH_R) * ZH_T + lx + ZH_R];
     }
-    if (__any(any) && (t & 63) == 0) atomicOr(&changed[img], 1);
+    if (__any(any) && (t & 63) == 0) { atomicOr(&changed[img], 1); tf_w[blockIdx.x] = 1; }
 }
 
 // converged <=> the last launch that could run removed nothing (its flag stayed 0)
@@ -338,7 +364,8 @@ size_t morph_workspace_bytes(int k, int H, int W)
     const size_t npx = (size_t)k * H * W;
     // seg, med, skA, skB (u8) + ML, SL, g, area, n1, n2, n3, fork, drop (int) + st (2 ints) + flags
     const int launches = ((H > W ? H : W) / 2 + 8 + ZH_IT - 1) / ZH_IT + 1;      // thinning launches (filter_edt_dev)
-    return npx * 4 + npx * sizeof(int) * 11 + (3 + (size_t)launches) * k * sizeof(int) + 4096;
+    const size_t tiles = (size_t)((W + ZH_TI - 1) / ZH_TI) * ((H + ZH_TI - 1) / ZH_TI);
+    return npx * 4 + npx * sizeof(int) * 11 + (3 + (size_t)launches + 3 * tiles) * k * sizeof(int) + 4096;
 }
 const int *morph_done_flags(void *workspace, int k, int H, int W)
 {
@@ -388,14 +415,15 @@ int filter_mask_dev(const double *pred, const uint8_t *mask_in, int k, int H, in
     const int max_pairs = (H > W ? H : W) / 2 + 8;
     const int launches = (max_pairs + ZH_IT - 1) / ZH_IT + 1;
     int *chg = flags + 3 * k;            // [launches][k]
-    if (hipMemsetAsync(flags, 0, (size_t)(3 + launches) * k * sizeof(int), s) != hipSuccess) { set_error("morph: memset"); return -2; }
     const int tiles_x = (W + ZH_TI - 1) / ZH_TI, tiles_y = (H + ZH_TI - 1) / ZH_TI;
+    int *tflags = chg + (size_t)launches * k;          // [3][k][tiles]: per-tile "removed something" of the launches it - 1, it, it + 1
+    if (hipMemsetAsync(flags, 0, (3 + (size_t)launches + 3 * (size_t)tiles_x * tiles_y) * k * sizeof(int), s) != hipSuccess) { set_error("morph: memset"); return -2; }
     const dim3 zgrid(tiles_x * tiles_y, k);
     for (int it = 0; it < launches; it++) {
         const uint8_t *src = (it & 1) ? skB : skA;
         uint8_t *dst = (it & 1) ? skA : skB;
         hipLaunchKernelGGL(zhang_tile_kernel, zgrid, blk, 0, s, src, dst, H, W, tiles_x, it ? chg + (size_t)(it - 1) * k : nullptr,
-                           chg + (size_t)it * k);
+                           chg + (size_t)it * k, tflags, it);
     }
     hipLaunchKernelGGL(zhang_done_kernel, dim3((k + 63) / 64), dim3(64), 0, s, chg + (size_t)(launches - 1) * k, done, k);
     // skeleton components, fork test, decision, filtered mask
