@@ -11,7 +11,7 @@
 #error "an *_ABL_* timing ablation (wrong results) is defined in a product build: ablations need -DTMAT_DEV_BUILD (tools/build_variant.sh)"
 #endif
 #if defined(TMAT_VAR_ORDER) || defined(TMAT_VAR_SETPRIO) || defined(TMAT_VAR_NOPIN) || defined(TMAT_OLD_MASKS) || \
-    defined(WS_POOL_SHUFFLE) || defined(TMAT_VAR_BUFSTORE) || defined(WS_VAR_SLEEP) || defined(WS_VAR_FETCHPRIO) || defined(ZH_VAR_NOSKIP)
+    defined(WS_POOL_SHUFFLE) || defined(TMAT_VAR_BUFSTORE) || defined(WS_VAR_SLEEP) || defined(WS_VAR_FETCHPRIO) || defined(ZH_VAR_NOSKIP) || defined(MA_VAR_NOSKIP)
 #error "a *_VAR_* kernel variant is defined in a product build: variants need -DTMAT_DEV_BUILD (tools/build_variant.sh)"
 #endif
 #if defined(TMAT_DIAG) || defined(WS_DIAG)

@@ -23,6 +23,7 @@
 //                     ping-pong between two copies of the bytes (every workgroup stages the same snapshot) and repeat until no image has an undone pixel (a flag per image; the depth of the DAG is about the largest
 //                     distance value: a few launches of ~30 us on all CUs instead of one wave per image for 20 ms).
 #include "tmat_internal.h"
+#include "dev_guard.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -144,7 +145,8 @@ __global__ __launch_bounds__(256) void ma_dep_kernel(const uint64_t *__restrict_
 constexpr int MA_T = 64, MA_R = 16, MA_S = MA_T + 2 * MA_R;      // tile, halo = rounds per launch, staged side
 __global__ __launch_bounds__(256) void ma_round_kernel(const uint8_t *__restrict__ sd, uint8_t *__restrict__ sd_out, const uint8_t *__restrict__ dep,
                                                        int H, int W, const uint32_t *__restrict__ table, int *__restrict__ undone,
-                                                       const int *__restrict__ active, uint8_t *__restrict__ tile_final)
+                                                       const int *__restrict__ active, uint8_t *__restrict__ tile_final, int *__restrict__ tprog,
+                                                       uint8_t *__restrict__ tile_left, int launch)
 {
     __shared__ uint8_t s_a[MA_S * MA_S];
     __shared__ uint8_t s_b[MA_S * MA_S];
@@ -155,8 +157,34 @@ __global__ __launch_bounds__(256) void ma_round_kernel(const uint8_t *__restrict
     const size_t per = (size_t)H * W;
     // A tile whose pixels were all done in the INPUT snapshot of some launch has been copied to the other snapshot by that
     // launch: both copies are final and every later launch skips it (its neighbours read final values from either copy).
-    uint8_t *final_flag = tile_final + ((size_t)img * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int ntiles = gridDim.x * gridDim.y, tile = blockIdx.y * gridDim.x + blockIdx.x;
+    uint8_t *final_flag = tile_final + (size_t)img * ntiles + tile;
+    // Tile activity (round 4): tprog[launch % 3][img][tile] = "a staged pixel of this tile became done in that launch".  A tile none of
+    // whose 3 x 3 neighbours (itself included) saw that in the previous launch has no ready pixel now -- readiness only changes when a
+    // predecessor becomes done, information moves 16 pixels per launch and the tiles are 64 wide -- and wrote nothing new then, so both
+    // snapshots already hold its pixels: it returns without staging anything, only repeating what it last said about undone pixels.
+    // (The slot of the next launch is cleared here: nobody reads it during this one.)
+    int *tp_w = tprog + ((size_t)(launch % 3) * gridDim.z + img) * ntiles;
+    const int *tp_r = tprog + ((size_t)((launch + 2) % 3) * gridDim.z + img) * ntiles;
+    if (threadIdx.x == 0) tprog[((size_t)((launch + 1) % 3) * gridDim.z + img) * ntiles + tile] = 0;
     if (*final_flag) return;
+    uint8_t *left_flag = tile_left + (size_t)img * ntiles + tile;
+    if (launch > 0) {
+#ifdef MA_VAR_NOSKIP
+        int act = 1;
+#else
+        int act = 0;
+#endif
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                const int yy = (int)blockIdx.y + dy, xx = (int)blockIdx.x + dx;
+                if (yy >= 0 && yy < (int)gridDim.y && xx >= 0 && xx < (int)gridDim.x) act |= tp_r[yy * gridDim.x + xx];
+            }
+        if (!act) {
+            if (threadIdx.x == 0 && *left_flag) atomicOr(&undone[img], 1);
+            return;
+        }
+    }
     const uint8_t *g_sd = sd + img * per;
     uint8_t *g_out = sd_out + img * per;
     const uint8_t *g_dp = dep + img * per;
@@ -188,6 +216,7 @@ __global__ __launch_bounds__(256) void ma_round_kernel(const uint8_t *__restrict
     }
     const bool inner_done_at_input = !__syncthreads_or(undone_inner);
     const bool work = __syncthreads_or(undone_here) && !idle;
+    bool progress = false;
     for (int r = 0; r < (work ? MA_R : 0); r++) {
         bool changed = false;
         // pixels on the rim of the staged area have neighbours that are not staged: they keep waiting (conservative)
@@ -212,6 +241,7 @@ __global__ __launch_bounds__(256) void ma_round_kernel(const uint8_t *__restrict
         const bool any_changed = __syncthreads_or(changed);
         uint8_t *tp = cur; cur = nxt; nxt = tp;
         if (!any_changed) break;            // a round that finishes nothing: nothing can become ready later in this launch
+        progress = true;
     }
     const uint8_t *s_sd = cur;
     bool left = false;
@@ -226,6 +256,7 @@ __global__ __launch_bounds__(256) void ma_round_kernel(const uint8_t *__restrict
     if (left) any = 1;
     __syncthreads();
     if (t == 0 && any) atomicOr(&undone[img], 1);
+    if (t == 0) { *left_flag = (uint8_t)(any != 0); if (progress) tp_w[tile] = 1; }
     if (t == 0 && inner_done_at_input) *final_flag = 1;
 }
 
@@ -240,7 +271,7 @@ size_t thin_workspace_bytes(int n, int H, int W)
 {
     const size_t per = (size_t)H * W;
     const size_t tiles = (size_t)((H + MA_T - 1) / MA_T) * ((W + MA_T - 1) / MA_T);
-    return (size_t)n * per * (8 + 1 + 1 + 1) + (size_t)n * 2 * sizeof(int) * 64 + (size_t)n * ((per + 1023) / 1024) * sizeof(int) + n * tiles + 1024;
+    return (size_t)n * per * (8 + 1 + 1 + 1) + (size_t)n * 2 * sizeof(int) * 64 + (size_t)n * ((per + 1023) / 1024) * sizeof(int) + n * tiles * (2 + 3 * sizeof(int)) + 1024;
 }
 
 int thin_count_dev(const uint8_t *mask, int n, int H, int W, int *nfg, hipStream_t s)
@@ -267,7 +298,9 @@ int thin_dev(const uint8_t *mask, const double *dist, const uint32_t *tie, const
     const int nchunk = (int)((per + 1023) / 1024);
     const size_t tiles = (size_t)((H + MA_T - 1) / MA_T) * ((W + MA_T - 1) / MA_T);
     uint8_t *tile_final = (uint8_t *)(chunk + (size_t)n * nchunk);                          // [image][tile]: both snapshots hold the tile's final values
-    if (hipMemsetAsync(tile_final, 0, (size_t)n * tiles, s) != hipSuccess) return -2;
+    uint8_t *tile_left = tile_final + (size_t)n * tiles;                                    // [image][tile]: the tile had undone pixels when it last ran
+    int *tprog = (int *)(((uintptr_t)(tile_left + (size_t)n * tiles) + 15) & ~(uintptr_t)15);      // [3][image][tile]: progress flags of launches l - 1, l, l + 1
+    if (hipMemsetAsync(tile_final, 0, (size_t)n * tiles * 2 + 16 + 3 * (size_t)n * tiles * sizeof(int), s) != hipSuccess) return -2;
     hipLaunchKernelGGL(ma_chunk_count_kernel, dim3(nchunk, n), dim3(1024), 0, s, mask, per, nchunk, chunk);
     hipLaunchKernelGGL(ma_chunk_scan_kernel, dim3(n), dim3(1024), 0, s, chunk, nchunk);
     hipLaunchKernelGGL(ma_keys_kernel, dim3(nchunk, n), dim3(1024), 0, s, mask, dist, H, W, tie, chunk, nchunk, keys);
@@ -281,7 +314,7 @@ int thin_dev(const uint8_t *mask, const double *dist, const uint32_t *tie, const
         if (hipMemsetAsync(flags, 0, (size_t)GROUP * n * sizeof(int), s) != hipSuccess) return -2;
         for (int g = 0; g < GROUP; g++) {                   // GROUP is even: the current copy is `sd` again after a group
             hipLaunchKernelGGL(ma_round_kernel, grid, dim3(256), 0, s, (g & 1) ? sd2 : sd, (g & 1) ? sd : sd2, dep, H, W, table_dev,
-                               flags + (size_t)g * n, g ? flags + (size_t)(g - 1) * n : (const int *)nullptr, tile_final);
+                               flags + (size_t)g * n, g ? flags + (size_t)(g - 1) * n : (const int *)nullptr, tile_final, tprog, tile_left, l + g);
         }
         if (hipMemcpyAsync(host.data(), flags + (size_t)(GROUP - 1) * n, n * sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess) return -2;
