@@ -160,8 +160,47 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
         return (n * a.h + yo * a.stride) * a.w + (r - yo * Wo) * a.stride;
     };
     const int p0 = flat ? m0 : __builtin_amdgcn_readfirstlane(stored_pixel(m0));
+    // Row-uniform form (round 4): a wave stages 8 consecutive output pixels per pass (rows 8 wave .. 8 wave + 7 of the pass), and with
+    // Wo % 8 == 0 those lie in ONE image row: (n, y) and the first column are wave-uniform, so the pixel -> (n, y, x) conversion, the row
+    // masks and the "past M" test run on the SCALAR unit (s_mul_hi_u32), and a lane only adds its column.  The generic form below costs
+    // ~35 vector instructions per pass, a dozen of them quarter-rate (v_mul_hi / v_mul_lo / v_mad_u64), and every vector instruction of an
+    // f32-MFMA kernel is matrix time: with K = 576 (the Cout = 64 layers) the prologue was 3 % of a tile.
+    const bool rowfast = !flat && (Wo & 7) == 0;
     unsigned pv[NPA];       // voffset (bytes) of the staged pixel's channel group
-    unsigned pm[NPA];       // mask of the taps that fall inside the image
+    unsigned pm[NPA];       // generic form: mask of the taps that fall inside the image
+    unsigned pvt[taps][NPA];
+    if (rowfast) {
+        // the lane's share of x and of the offset, made once (opaque to the optimiser, which otherwise folds them back into per-pass multiplies)
+        int lx = (lane >> 3) * a.stride;
+        unsigned lane_pv = (unsigned)(lx * a.Cin + c4) * 4u;
+        asm volatile("" : "+v"(lx), "+v"(lane_pv));
+#pragma unroll
+        for (int i = 0; i < NPA; i++) {
+            const int mb = m0 + i * RP + wave * 8;           // uniform; M % 8 == 0, so the 8 pixels are inside M or past it together
+            const bool ok = mb < M;
+            const int mm = ok ? mb : m0;
+            const int n = fdiv(mm, dHW);
+            const int r = mm - n * (Ho * Wo);
+            const int yo = fdiv(r, dW);
+            const int y = yo * a.stride, xs = (r - yo * Wo) * a.stride;
+            const int x = xs + lx;
+            pv[i] = (unsigned)(((n * a.h + y) * a.w + xs - p0) * a.Cin) * 4u + lane_pv;
+            if (KS == 3) {
+                const unsigned pl = x > 0 ? pv[i] : OOB, pr = x + 1 < a.w ? pv[i] : OOB;
+                const bool y0 = ok && y > 0, y2 = ok && y + 1 < a.h;
+                pvt[0][i] = y0 ? pl : OOB; pvt[1][i] = y0 ? pv[i] : OOB; pvt[2][i] = y0 ? pr : OOB;
+                pvt[3 % taps][i] = ok ? pl : OOB; pvt[4 % taps][i] = ok ? pv[i] : OOB; pvt[5 % taps][i] = ok ? pr : OOB;
+                pvt[6 % taps][i] = y2 ? pl : OOB; pvt[7 % taps][i] = y2 ? pv[i] : OOB; pvt[8 % taps][i] = y2 ? pr : OOB;
+            } else if (KS == 2) {       // tap tp: row y + spy - 1 + (tp >> 1), column x + spx - 1 + (tp & 1)
+                const unsigned pl = x + spx > 0 ? pv[i] : OOB, pr = x + spx < a.w ? pv[i] : OOB;
+                const bool y0 = ok && y + spy > 0, y1 = ok && y + spy < a.h;
+                pvt[0][i] = y0 ? pl : OOB; pvt[1 % taps][i] = y0 ? pr : OOB;
+                pvt[2 % taps][i] = y1 ? pl : OOB; pvt[3 % taps][i] = y1 ? pr : OOB;
+            } else {
+                pvt[0][i] = ok ? pv[i] : OOB;
+            }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < NPA; i++) {
         const int m = m0 + i * RP + srow;
@@ -179,21 +218,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
         pv[i] = (unsigned)(((n * a.h + y) * a.w + x - p0) * a.Cin + c4) * 4u;
         // tap masks without branches: bit ky * 3 + kx is set when row y + ky - 1 and column x + kx - 1 lie inside the image
         unsigned msk = 1u;
-#ifdef TMAT_OLD_MASKS
-        if (KS == 3) {
-            msk = 0;
-            for (int tp = 0; tp < 9; tp++) {
-                const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
-                if (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) msk |= 1u << tp;
-            }
-        } else if (KS == 2) {
-            msk = 0;
-            for (int tp = 0; tp < 4; tp++) {
-                const int yy = y + spy - 1 + (tp >> 1), xx = x + spx - 1 + (tp & 1);
-                if (yy >= 0 && yy < a.h && xx >= 0 && xx < a.w) msk |= 1u << tp;
-            }
-        }
-#else
         if (KS == 3) {
             const unsigned ym = (y > 0 ? 0x007u : 0u) | 0x038u | (y + 1 < a.h ? 0x1C0u : 0u);
             const unsigned xm = (x > 0 ? 0x049u : 0u) | 0x092u | (x + 1 < a.w ? 0x124u : 0u);
@@ -203,9 +227,19 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
             const unsigned xm = (x + spx > 0 ? 0x5u : 0u) | (x + spx < a.w ? 0xAu : 0u);
             msk = ym & xm;
         }
-#endif
         if (!ok) msk = 0u;
         pm[i] = msk;
+    }
+    // Per-tap scalars and per-(tap, pass) lane offsets, made ONCE per tile (round 4).  Rounds 1-3 derived them per chunk from a runtime tap
+    // counter: ~25 scalar instructions (tap -> (dy, dx) -> offsets, wrap) and, per A pass, v_and / v_cmp / v_cndmask to pick the lane's offset
+    // or the out-of-range constant -- 6 vector instructions per chunk next to 16-32 MFMAs, and vector instructions do not issue beside f32
+    // MFMAs (DESIGN 4).  The K loop below is unrolled over the taps (18 chunks for 3 x 3: two channel blocks, so that the stage parity
+    // repeats; 4 for the sub-pixel form; 2 for 1 x 1), which makes the tap of every DMA a compile-time constant: its scalar offsets are
+    // two s_add, its lane offsets live in registers (taps x NPA <= 18; the kernels use 58-86 of their 128).
+#pragma unroll
+    for (int tp = 0; tp < taps; tp++)
+#pragma unroll
+        for (int i = 0; i < NPA; i++) pvt[tp][i] = ((pm[i] >> tp) & 1u) ? pv[i] : OOB;
     }
     const __amdgpu_buffer_rsrc_t rsA =
         __builtin_amdgcn_make_buffer_rsrc((void *)(a.in + ((long)p0 - a.w - 1) * a.Cin), 0, 0x7fffffff, 0x00020000);
@@ -222,17 +256,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
     const int wpass = RP * a.Cin * 4;                // bytes per DMA pass of weight rows
     const int ldsw = wave * 8 * KC;                  // this wave's 8 rows (1 KiB) inside an RP-row pass
 
-    // Per-tap scalars and per-(tap, pass) lane offsets, made ONCE per tile (round 4).  Rounds 1-3 derived them per chunk from a runtime tap
-    // counter: ~25 scalar instructions (tap -> (dy, dx) -> offsets, wrap) and, per A pass, v_and / v_cmp / v_cndmask to pick the lane's offset
-    // or the out-of-range constant -- 6 vector instructions per chunk next to 16-32 MFMAs, and vector instructions do not issue beside f32
-    // MFMAs (DESIGN 4).  The K loop below is unrolled over the taps (18 chunks for 3 x 3: two channel blocks, so that the stage parity
-    // repeats; 4 for the sub-pixel form; 2 for 1 x 1), which makes the tap of every DMA a compile-time constant: its scalar offsets are
-    // two s_add, its lane offsets live in registers (taps x NPA <= 18; the kernels use 58-86 of their 128).
-    unsigned pvt[taps][NPA];
-#pragma unroll
-    for (int tp = 0; tp < taps; tp++)
-#pragma unroll
-        for (int i = 0; i < NPA; i++) pvt[tp][i] = ((pm[i] >> tp) & 1u) ? pv[i] : OOB;
+    // (pvt[tap][pass], the per-(tap, pass) lane offsets of the A DMA, were made above, once per tile)
     // scalar offsets of the chunk to load next, advanced by compile-time-selected steps (tap -> next tap in the row, next row, wrap to the
     // next channel block): A: ((dy + 1) w + dx + 1) Cin + 32 cb floats from the descriptor base; B: tap * wtap + 32 cb
     const int a_cstep = a.Cin * 4;                                                   // next tap of the same row
@@ -532,16 +556,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
         constexpr int WPS = (WM * WN) / 2;                   // waves per stage
         static_assert(PW * WPS <= STAGE, "wave-private epilogue slabs fit the two stages");
         float *Ws = (wave < WPS ? stage0 : stage1) + (wave % WPS) * PW;
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-#pragma unroll
-                for (int jn = 0; jn < TN; jn++) Ws[row * WCOLS + jn * 32 + (lane & 31)] = acc[i][jn][r];
-            }
+        constexpr int NIT = WROWS / RPW;                     // store iterations: RPW consecutive output pixels each
         const int quad = lane % V4W, rsub = lane / V4W;
-        const int co = n0 + wn * (BN / WN) + quad * 4;
+        const int cbase = n0 + wn * (BN / WN);
+        const int co = cbase + quad * 4;
         // no scale (plain bias): fmaf(v, 1, shift) is v + shift bit for bit (the product is exact, one rounding), so the loop below has ONE
         // form -- with `a.scale ? fmaf : add` hipcc evaluated both and selected per value (2 v_pk_add + 4 v_cndmask per 16-byte row, and
         // every vector instruction of an f32-MFMA kernel is matrix time: DESIGN 4)
@@ -552,34 +570,76 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 16 ? 4 : (BM + BN) * 256 
         const int mw = m0 + wm * (BM / WM);                  // first output pixel of the wave's block
         const bool full = mw + WROWS <= M;
         const unsigned vo = (unsigned)(rsub * a.Cout + quad * 4) * 4u;
-        const size_t tbase = (size_t)mw * a.Cout + n0 + wn * (BN / WN);
+        const size_t tbase = (size_t)mw * a.Cout + cbase;
         char *const obase = reinterpret_cast<char *>(a.out + tbase);
         char *const o2base = reinterpret_cast<char *>(a.out_relu + tbase);                // used when a.out_relu only
         const char *const rbase = reinterpret_cast<const char *>(a.resid + tbase);       // used for rs == 0 only
-#pragma unroll 4
-        for (int it = 0; it < WROWS / RPW; it++) {
-            const int row = it * RPW + rsub;
-            const int m = mw + row;
-            const bool ok = full || m < M;
-            const size_t so = (size_t)(it * RPW) * a.Cout * 4;
-            float4 v = *reinterpret_cast<const float4 *>(Ws + row * WCOLS + quad * 4);
-            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-            if (a.resid) {
+        // Row-uniform form of the two index-heavy paths (the low-resolution residual, rs != 0, and the sub-pixel scatter, KS == 2; round 4):
+        // an iteration handles RPW consecutive output pixels starting at a multiple of RPW; with Wo % RPW == 0 they lie in one image row
+        // (and, M being a multiple of RPW then, inside M or past it together), so pixel -> (n, y, x) is SCALAR arithmetic (s_mul_hi_u32) on
+        // the iteration's first pixel and a lane adds a kernel-constant offset.  The per-lane form cost ~23 vector instructions per iteration,
+        // ten of them quarter-rate 32 / 64-bit multiplies: 4-5 % of a K = 576 tile (every vector instruction here is matrix time).
+        const bool efast = (Wo % RPW) == 0 && (RPW >> a.rs) >= 1;
+        const unsigned vo_r = (unsigned)((rsub >> a.rs) * a.Cout + quad * 4) * 4u;         // low-resolution residual: column (x0 + rsub) >> rs
+        const unsigned vo_s = (unsigned)(2 * rsub * a.Cout + quad * 4) * 4u;               // sub-pixel scatter: column 2 (x0 + rsub) + spx
+        // The residual rows are requested FIRST, all NIT of them, before the accumulators go through LDS: one wait for the lot under the
+        // transposition instead of a vmcnt(0) per iteration (which also waited for the previous iteration's store).
+        float4 rvs[NIT];
+        if (a.resid) {
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
                 float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int m_it = mw + it * RPW;
                 if (a.rs) {
-                    if (ok) {
+                    if (efast) {
+                        if (full || m_it < M) {
+                            const int un = fdiv(m_it, dHW);
+                            const int rr = m_it - un * (Ho * Wo);
+                            const int uy = fdiv(rr, dW), ux = rr - uy * Wo;
+                            const size_t ridx = ((size_t)un * rH + (uy >> a.rs)) * rW + (ux >> a.rs);
+                            rv = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.resid + ridx * a.Cout + cbase) + vo_r);
+                        }
+                    } else if (full || m_it + rsub < M) {
+                        const int m = m_it + rsub;
                         const int n = fdiv(m, dHW);
                         const int rr = m - n * (Ho * Wo);
                         const int y = fdiv(rr, dW), x = rr - y * Wo;
                         const size_t ridx = ((size_t)n * rH + (y >> a.rs)) * rW + (x >> a.rs);
                         rv = *reinterpret_cast<const float4 *>(a.resid + ridx * a.Cout + co);
                     }
-                } else if (ok) rv = *reinterpret_cast<const float4 *>(rbase + so + vo);
-                v.x = v.x + rv.x; v.y = v.y + rv.y; v.z = v.z + rv.z; v.w = v.w + rv.w;
+                } else if (full || m_it + rsub < M) rv = *reinterpret_cast<const float4 *>(rbase + (size_t)(it * RPW) * a.Cout * 4 + vo);
+                rvs[it] = rv;
             }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+                for (int jn = 0; jn < TN; jn++) Ws[row * WCOLS + jn * 32 + (lane & 31)] = acc[i][jn][r];
+            }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int row = it * RPW + rsub;
+            const int m = mw + row;
+            const bool ok = full || m < M;
+            const size_t so = (size_t)(it * RPW) * a.Cout * 4;
+            float4 v = *reinterpret_cast<const float4 *>(Ws + row * WCOLS + quad * 4);
+            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+            if (a.resid) { const float4 rv = rvs[it]; v.x = v.x + rv.x; v.y = v.y + rv.y; v.z = v.z + rv.z; v.w = v.w + rv.w; }
             if (a.relu_out) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }      // uniform branch
             if (KS == 2) {      // scatter to the parity class's pixels of the (2 Ho, 2 Wo) output
-                if (ok) {
+                if (efast) {
+                    const int m_it = mw + it * RPW;
+                    if (full || m_it < M) {
+                        const int un = fdiv(m_it, dHW);
+                        const int rr = m_it - un * (Ho * Wo);
+                        const int uy = fdiv(rr, dW), ux = rr - uy * Wo;
+                        const size_t oidx = ((size_t)un * 2 * Ho + 2 * uy + spy) * (2 * Wo) + 2 * ux + spx;
+                        *reinterpret_cast<float4 *>(reinterpret_cast<char *>(a.out + oidx * a.Cout + cbase) + vo_s) = v;
+                    }
+                } else if (ok) {
                     const int n = fdiv(m, dHW);
                     const int rr = m - n * (Ho * Wo);
                     const int y = fdiv(rr, dW), x = rr - y * Wo;
