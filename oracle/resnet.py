@@ -10,8 +10,9 @@ ZeroPadding2D(1) + 3x3/2 'valid' max-pool, bottleneck blocks with the stride in 
 shortcut of a stage's first block).  What the reference's own files do pin is the ensemble selection: the
 best_model_history_*.csv files are read exactly as compute_inv_depth.py:86-93 reads them (tests/golden/inv_depth_histories).
 
-Arithmetic: 1x1 / 3x3 convolutions through oracle/unet_exact.c:orc_conv (the chain order of the MFMA kernel); stem, pool and head
-in float32 numpy with multiply and add kept separate, in the order csrc/resnet_kernels.hip documents.
+Arithmetic: 1x1 / 3x3 convolutions AND the 7x7 stem (as a 1x1 convolution over its im2col tensor, 147 taps padded to K = 192) through
+oracle/unet_exact.c:orc_conv (the chain order of the MFMA kernel); pool and head in float32 numpy with multiply and add kept
+separate, in the order csrc/resnet_kernels.hip documents.
 """
 from __future__ import annotations
 
@@ -48,19 +49,30 @@ def prep_inv_depth_imgs(stack: np.ndarray, size: int = 256) -> np.ndarray:
     return out
 
 
-def stem(x, w, scale, shift):
-    """ZeroPadding2D(3) + Conv2D(64, 7, strides 2) + BN + ReLU; chain (ky, kx, c) from +0.0, acc = acc + v * w"""
+STEM_TAPS, STEM_K = 147, 192
+
+
+def stem_im2col(x):
+    """(N, S, S, 3) -> (N, S/2, S/2, 192): the 147 taps of ZeroPadding2D(3) + Conv2D(64, 7, strides 2) per output pixel, k = (ky 7 + kx) 3 + c,
+    zeros outside the image and for k >= 147 (csrc/resnet_kernels.hip:resnet_im2col_kernel)"""
     N, S = x.shape[0], x.shape[1]
     So = S // 2
     xp = np.zeros((N, S + 6, S + 6, 3), np.float32)
     xp[:, 3:-3, 3:-3] = x
-    acc = np.zeros((N, So, So, 64), np.float32)
+    col = np.zeros((N, So, So, STEM_K), np.float32)
     for ky in range(7):
         for kx in range(7):
-            win = xp[:, ky:ky + 2 * So:2, kx:kx + 2 * So:2]
-            for c in range(3):
-                acc = acc + win[..., c:c + 1] * w[ky, kx, c][None, None, None, :]
-    return np.maximum(acc * scale + shift, F32(0))
+            k = (ky * 7 + kx) * 3
+            col[..., k:k + 3] = xp[:, ky:ky + 2 * So:2, kx:kx + 2 * So:2]
+    return col
+
+
+def stem(x, w, scale, shift):
+    """ZeroPadding2D(3) + Conv2D(64, 7, strides 2) + BN + ReLU as a 1x1 convolution over the im2col tensor: orc_conv's chain over
+    k (the order conv_mfma_kernel accumulates in), fmaf(acc, scale, shift), ReLU"""
+    wk = np.zeros((1, 1, STEM_K, 64), np.float32)
+    wk[0, 0, :STEM_TAPS] = w.reshape(STEM_TAPS, 64)
+    return ou._conv(stem_im2col(np.ascontiguousarray(x, np.float32)), wk, 1, 1, 0, 0, scale, shift, None, 0, 1)
 
 
 def pool(x):

@@ -9,8 +9,12 @@
 // max-pool and the head.  Keras details: every Conv2D has a bias, BatchNormalization eps = 1.001e-5, ZeroPadding2D(3) before
 // the stem convolution and ZeroPadding2D(1) before the pool (both 'valid'), the stride of a stage sits in the first 1x1
 // convolution of its first block and in that block's projection shortcut.
-// Arithmetic of the new kernels (shared with oracle/resnet.py): float32, multiply and add kept separate (no FMA), chains in
-// (ky, kx, channel) order from +0.0; head: per channel sum over the 256 pixels in raster order, times 1/256, dot product over
+// The 7x7 stride-2 stem runs on the same MFMA kernel (round 4): resnet_im2col_kernel lays the 147 taps of every output pixel out as
+// a 192-channel pixel (k = (ky 7 + kx) 3 + c, zeros outside the image and for k >= 147: six K chunks of 32) and the convolution
+// becomes a 1x1 layer with K = 192; round 3's direct kernel (one thread per output, 147 LDS + 147 cached global reads each) took
+// 18 % of the tool's GPU time at 12 TFLOP/s.
+// Arithmetic of the new kernels (shared with oracle/resnet.py): float32, multiply and add kept separate (no FMA) in pool and
+// head; stem: orc_conv's chain over k (the MFMA order) on the im2col tensor, fmaf(acc, scale, shift), ReLU; head: per channel sum over the 256 pixels in raster order, times 1/256, dot product over
 // the channels in order, plus bias, 1 / (1 + exp_det(-z)).
 #include "../../include/tmat.h"
 #include "tmat_ctx.h"
@@ -50,36 +54,30 @@ __global__ __launch_bounds__(256) void minmax_u16_img_kernel(const uint16_t *__r
     }
 }
 
-// conv1: ZeroPadding2D(3) + Conv2D(64, 7, strides 2, valid) + BN + ReLU.  x (N, S, S, 3) -> out (N, S/2, S/2, 64).
-// One thread = one output value; a block = 4 output pixels x 64 channels; the 147 x 64 weights sit in LDS.
-__global__ __launch_bounds__(256) void resnet_stem_kernel(const float *__restrict__ x, int S, const float *__restrict__ w, const float *__restrict__ scale,
-                                                          const float *__restrict__ shift, float *__restrict__ out)
+// conv1: ZeroPadding2D(3) + Conv2D(64, 7, strides 2, valid) + BN + ReLU, as im2col + a 1x1 convolution on conv_mfma_kernel.
+// x (N, S, S, 3) -> col (N, S/2, S/2, 192): col[k] = x[2 yo + ky - 3][2 xo + kx - 3][c] for k = (ky 7 + kx) 3 + c < 147 (0 outside the
+// image: the zero padding), 0 for 147 <= k < 192.  One thread = 4 consecutive k of one output pixel (one 16-byte store).
+constexpr int STEM_TAPS = 147, STEM_K = 192;
+__global__ __launch_bounds__(256) void resnet_im2col_kernel(const float *__restrict__ x, int S, float *__restrict__ col, size_t total)
 {
-    __shared__ float sw[147 * 64];
-    for (int i = threadIdx.x; i < 147 * 64; i += 256) sw[i] = w[i];
-    __syncthreads();
     const int So = S >> 1;
-    const int n = blockIdx.y;
-    const int co = threadIdx.x & 63;
-    const float *xi = x + (size_t)n * S * S * 3;
-    for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < So * So; p += gridDim.x * 4) {
-        const int yo = p / So, xo = p - yo * So;
-        float acc = 0.0f;
-        for (int ky = 0; ky < 7; ky++) {
-            const int iy = 2 * yo + ky - 3;
-            for (int kx = 0; kx < 7; kx++) {
-                const int ix = 2 * xo + kx - 3;
-                const bool in = iy >= 0 && iy < S && ix >= 0 && ix < S;
-                const float *px = xi + ((size_t)(in ? iy : 0) * S + (in ? ix : 0)) * 3;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int q = (int)(e % (STEM_K / 4));
+        const size_t pix = e / (STEM_K / 4);
+        const int xo = (int)(pix % So), yo = (int)((pix / So) % So);
+        const size_t n = pix / ((size_t)So * So);
+        const float *xi = x + n * S * S * 3;
+        float v[4];
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const float v = in ? px[c] : 0.0f;
-                    acc = acc + v * sw[((ky * 7 + kx) * 3 + c) * 64 + co];
-                }
-            }
+        for (int j = 0; j < 4; j++) {
+            const int k = 4 * q + j;
+            const int tap = k / 3, c = k - tap * 3;
+            const int ky = tap / 7, kx = tap - ky * 7;
+            const int iy = 2 * yo + ky - 3, ix = 2 * xo + kx - 3;
+            const bool in = k < STEM_TAPS && iy >= 0 && iy < S && ix >= 0 && ix < S;
+            v[j] = in ? xi[((size_t)iy * S + ix) * 3 + c] : 0.0f;
         }
-        const float y = acc * scale[co] + shift[co];
-        out[((size_t)n * So * So + p) * 64 + co] = fmaxf(y, 0.0f);
+        *reinterpret_cast<float4 *>(col + e * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -185,15 +183,19 @@ static bool run_conv(const ResConv &c, const float *in, int N, int h, const floa
     return launch_conv(a, s);
 }
 
-// x (N, S, S, 3) f32 on the device -> prob (N) on the device; bufs: 4 activation buffers of N * (S/2)^2 * 64 floats
-static int resnet_forward_dev(const ResNetModel &m, const float *x, int N, int S, float *const bufs[4], float *prob, hipStream_t s)
+// x (N, S, S, 3) f32 on the device -> prob (N) on the device; bufs: 4 activation buffers of N * (S/2)^2 * 64 floats; col: N * (S/2)^2 * 192
+static int resnet_forward_dev(const ResNetModel &m, const float *x, int N, int S, float *const bufs[4], float *col, float *prob, hipStream_t s)
 {
     float *a = bufs[0], *b = bufs[1], *t1 = bufs[2], *t2 = bufs[3];
     const int S2 = S / 2, S4 = S / 4;
-    // every workgroup first copies the 37 KB of stem weights to LDS: give it enough pixels to pay for that (round 2 launched
-    // one workgroup per 4 output pixels, i.e. 37 KB of LDS fill per 256 outputs; the grid-stride loop was never taken)
-    const int stem_blocks = std::max(1, std::min(S2 * S2 / 4, std::max(8, 2048 / std::max(N, 1))));
-    hipLaunchKernelGGL(resnet_stem_kernel, dim3(stem_blocks, N), dim3(256), 0, s, x, S, m.stem_w, m.stem_scale, m.stem_shift, a);
+    {
+        const size_t quads = (size_t)N * S2 * S2 * (STEM_K / 4);
+        hipLaunchKernelGGL(resnet_im2col_kernel, dim3((unsigned)std::min<size_t>((quads + 255) / 256, 1u << 20)), dim3(256), 0, s, x, S, col, quads);
+        ConvArgs st{};
+        st.in = col; st.N = N; st.h = S2; st.w = S2; st.Cin = STEM_K; st.relu_in = 0; st.ksize = 1; st.stride = 1; st.W = m.stem_w; st.Cout = 64;
+        st.scale = m.stem_scale; st.shift = m.stem_shift; st.resid = nullptr; st.rs = 0; st.relu_out = 1; st.out = a;
+        if (!launch_conv(st, s)) return TMAT_E_ARG;
+    }
     const size_t ptotal = (size_t)N * S4 * S4 * 64;
     hipLaunchKernelGGL(resnet_pool_kernel, dim3((unsigned)std::min<size_t>((ptotal + 255) / 256, 16384)), dim3(256), 0, s, a, S2, 64, b, ptotal);
     float *cur = b, *nxt = a;
@@ -236,14 +238,17 @@ int tmat_resnet_load(tmat_handle hd, const void *weights_blob, size_t n_bytes, i
     if (!parse_blob(weights_blob, n_bytes, t, patch)) return TMAT_E_WEIGHTS;
     ResNetModel m;
     auto fail = [&]() { for (void *p : m.owned) hipFree(p); return TMAT_E_WEIGHTS; };
-    // stem: (7, 7, 3, 64) -> [147][64] as stored; BN folded with the convolution's bias
+    // stem: BN folded with the convolution's bias
     auto sw = t.find("conv1.w"), sb = t.find("conv1.b"), sbn = t.find("conv1.bn");
     if (sw == t.end() || sb == t.end() || sbn == t.end() || sw->second.shape != std::vector<int>({7, 7, 3, 64}) || sbn->second.shape != std::vector<int>({4, 64}) ||
         sb->second.count != 64) { set_error("resnet weights: conv1 missing or malformed"); return fail(); }
     {
         std::vector<float> sc, sh;
         fold_bn_keras(sbn->second, sb->second, sc, sh);
-        if (!up(m, std::vector<float>(sw->second.data, sw->second.data + sw->second.count), &m.stem_w) || !up(m, sc, &m.stem_scale) || !up(m, sh, &m.stem_shift)) return fail();
+        // (7, 7, 3, 64) = [147][64] as stored -> [64][192], k contiguous (conv_mfma_kernel's weight layout), zeros for k >= 147
+        std::vector<float> wk((size_t)64 * STEM_K, 0.0f);
+        for (int k = 0; k < STEM_TAPS; k++) for (int o = 0; o < 64; o++) wk[(size_t)o * STEM_K + k] = sw->second.data[(size_t)k * 64 + o];
+        if (!up(m, wk, &m.stem_w) || !up(m, sc, &m.stem_scale) || !up(m, sh, &m.stem_shift)) return fail();
     }
     int cin = 64;
     for (int stage = 2;; stage++) {
@@ -279,14 +284,15 @@ int tmat_resnet_predict(tmat_handle hd, int model_id, const float *x, int n, int
     TMAT_HIP(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const size_t nx = (size_t)n * size * size * 3, nb = (size_t)n * (size / 2) * (size / 2) * 64;
-    float *dx = nullptr, *dp = nullptr, *bufs[4] = {nullptr, nullptr, nullptr, nullptr};
+    float *dx = nullptr, *dp = nullptr, *col = nullptr, *bufs[4] = {nullptr, nullptr, nullptr, nullptr};
     int rc = TMAT_OK;
-    if (!hip_ok(hipMalloc((void **)&dx, nx * 4), "hipMalloc") || !hip_ok(hipMalloc((void **)&dp, n * 4), "hipMalloc")) rc = TMAT_E_HIP;
+    if (!hip_ok(hipMalloc((void **)&dx, nx * 4), "hipMalloc") || !hip_ok(hipMalloc((void **)&dp, n * 4), "hipMalloc") ||
+        !hip_ok(hipMalloc((void **)&col, nb * 3 * 4), "hipMalloc")) rc = TMAT_E_HIP;      // 192 = 3 x 64 values per stem output pixel
     for (int i = 0; i < 4 && !rc; i++) if (!hip_ok(hipMalloc((void **)&bufs[i], nb * 4), "hipMalloc")) rc = TMAT_E_HIP;
     if (!rc && !hip_ok(hipMemcpyAsync(dx, x, nx * 4, hipMemcpyHostToDevice, s), "H2D")) rc = TMAT_E_HIP;
-    if (!rc) rc = resnet_forward_dev(c->resnets[model_id], dx, n, size, bufs, dp, s);
+    if (!rc) rc = resnet_forward_dev(c->resnets[model_id], dx, n, size, bufs, col, dp, s);
     if (!rc && (!hip_ok(hipMemcpyAsync(prob, dp, n * 4, hipMemcpyDeviceToHost, s), "D2H") || !hip_ok(hipStreamSynchronize(s), "sync"))) rc = TMAT_E_HIP;
-    hipFree(dx); hipFree(dp);
+    hipFree(dx); hipFree(dp); hipFree(col);
     for (float *b : bufs) hipFree(b);
     return rc;
 }
@@ -303,7 +309,7 @@ int tmat_inv_depth_predict(tmat_handle hd, const int *model_ids, int n_models, c
     const size_t npx = (size_t)size * size;
     uint16_t *din = nullptr, *dsm = nullptr;
     int *itab = nullptr, *mnmx = nullptr;
-    float *dx = nullptr, *dp = nullptr, *bufs[4] = {nullptr, nullptr, nullptr, nullptr};
+    float *dx = nullptr, *dp = nullptr, *col = nullptr, *bufs[4] = {nullptr, nullptr, nullptr, nullptr};
     // cv2.resize(img, img_hw, cv2.INTER_LANCZOS4) (data_prep.py:36): the third positional parameter is `dst`: bilinear
     int rc = TMAT_OK;
     const int nb = std::min(Z, CH);
@@ -312,6 +318,7 @@ int tmat_inv_depth_predict(tmat_handle hd, const int *model_ids, int n_models, c
         !hip_ok(hipMalloc((void **)&mnmx, (size_t)Z * 2 * 4), "hipMalloc") || !hip_ok(hipMalloc((void **)&dx, (size_t)Z * npx * 3 * 4), "hipMalloc") ||
         !hip_ok(hipMalloc((void **)&dp, (size_t)Z * n_models * 4), "hipMalloc")) rc = TMAT_E_HIP;
     for (int i = 0; i < 4 && !rc; i++) if (!hip_ok(hipMalloc((void **)&bufs[i], (size_t)nb * (size / 2) * (size / 2) * 64 * 4), "hipMalloc")) rc = TMAT_E_HIP;
+    if (!rc && !hip_ok(hipMalloc((void **)&col, (size_t)nb * (size / 2) * (size / 2) * STEM_K * 4), "hipMalloc")) rc = TMAT_E_HIP;
     if (!rc) {
         // cv::resize takes INTER_AREA's integer mean for an exact halving on both axes (a 512 x 512 slice at the configured 256 x 256);
         // 8-bit sources (tmat_set_input_depth(h, 8)) take its fixed-point bilinear arithmetic
@@ -325,7 +332,7 @@ int tmat_inv_depth_predict(tmat_handle hd, const int *model_ids, int n_models, c
             for (int mi = 0; mi < n_models && !rc; mi++)
                 for (int z0 = 0; z0 < Z && !rc; z0 += CH) {
                     const int k = std::min(CH, Z - z0);
-                    rc = resnet_forward_dev(c->resnets[model_ids[mi]], dx + (size_t)z0 * npx * 3, k, size, bufs, dp + (size_t)mi * Z + z0, s);
+                    rc = resnet_forward_dev(c->resnets[model_ids[mi]], dx + (size_t)z0 * npx * 3, k, size, bufs, col, dp + (size_t)mi * Z + z0, s);
                 }
             std::vector<float> ph((size_t)Z * n_models);
             if (!rc && (!hip_ok(hipMemcpyAsync(ph.data(), dp, ph.size() * 4, hipMemcpyDeviceToHost, s), "D2H") ||
@@ -334,7 +341,7 @@ int tmat_inv_depth_predict(tmat_handle hd, const int *model_ids, int n_models, c
             if (!rc) for (int z = 0; z < Z; z++) for (int mi = 0; mi < n_models; mi++) probs[(size_t)z * n_models + mi] = ph[(size_t)mi * Z + z];     // (Z, n_models)
         }
     }
-    hipFree(din); hipFree(dsm); hipFree(itab); hipFree(mnmx); hipFree(dx); hipFree(dp);
+    hipFree(din); hipFree(dsm); hipFree(itab); hipFree(mnmx); hipFree(dx); hipFree(dp); hipFree(col);
     for (float *b : bufs) hipFree(b);
     return rc;
 }
