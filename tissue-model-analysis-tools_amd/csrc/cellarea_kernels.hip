@@ -347,13 +347,16 @@ static int cell_area_impl(tmat_handle hd, const uint16_t *imgs, int n, int H, in
     int *itab = nullptr;
     int rc = TMAT_OK;
     auto fail = [&](int code) { rc = code; };
-    if (!hip_ok(hipMalloc((void **)&din, nin * 2), "hipMalloc") || !hip_ok(hipMalloc((void **)&hist, (size_t)n * 65536 * 4), "hipMalloc") ||
-        !hip_ok(hipMalloc((void **)&kept, n * 4), "hipMalloc") || !hip_ok(hipMalloc((void **)&dpar, (size_t)n * 11 * 8), "hipMalloc") ||
-        (thresholded && !hip_ok(hipMalloc((void **)&dthr, nout), "hipMalloc"))) fail(TMAT_E_HIP);
+    // workspaces live on the handle between calls (tmat_ctx.h:ws_get): slots 0..8 of this tool
+    din = (uint16_t *)ws_get(c, 0, nin * 2); hist = (unsigned *)ws_get(c, 1, (size_t)n * 65536 * 4);
+    kept = (unsigned *)ws_get(c, 2, (size_t)n * 4); dpar = (double *)ws_get(c, 3, (size_t)n * 11 * 8);
+    if (thresholded) dthr = (uint8_t *)ws_get(c, 4, nout);
+    if (!din || !hist || !kept || !dpar || (thresholded && !dthr)) fail(TMAT_E_HIP);
     if (!rc && !hip_ok(hipMemcpyAsync(din, imgs, nin * 2, hipMemcpyHostToDevice, s), "H2D")) fail(TMAT_E_HIP);
     const uint16_t *small = din;
     if (!rc && out_h) {
-        if (!hip_ok(hipMalloc((void **)&dsm, nout * 2), "hipMalloc") || !hip_ok(hipMalloc((void **)&itab, (size_t)(oh + ow) * 4 * 4), "hipMalloc")) fail(TMAT_E_HIP);
+        dsm = (uint16_t *)ws_get(c, 5, nout * 2); itab = (int *)ws_get(c, 6, (size_t)(oh + ow) * 4 * 4);
+        if (!dsm || !itab) fail(TMAT_E_HIP);
         // 8-bit sources (tmat_set_input_depth(h, 8)) take cv2's fixed-point arithmetic
         else if (launch_resize_linear_dev(din, n, H, W, oh, ow, c->input_sat == 255.f, itab, dsm, s)) fail(TMAT_E_HIP);
         else small = dsm;
@@ -373,7 +376,8 @@ static int cell_area_impl(tmat_handle hd, const uint16_t *imgs, int n, int H, in
             if (!rc && masks) {
                 std::vector<int> init((size_t)2 * n);
                 for (int i = 0; i < n; i++) { init[2 * i] = 65536; init[2 * i + 1] = -1; }
-                if (!hip_ok(hipMalloc((void **)&dmaskbuf, nout), "hipMalloc") || !hip_ok(hipMalloc((void **)&lohibuf, (size_t)2 * n * 4), "hipMalloc") ||
+                dmaskbuf = (uint8_t *)ws_get(c, 7, nout); lohibuf = (int *)ws_get(c, 8, (size_t)2 * n * 4);
+                if (!dmaskbuf || !lohibuf ||
                     !hip_ok(hipMemcpyAsync(dmaskbuf, masks, nout, hipMemcpyHostToDevice, s), "H2D") ||
                     !hip_ok(hipMemcpy(lohibuf, init.data(), init.size() * 4, hipMemcpyHostToDevice), "H2D")) fail(TMAT_E_HIP);
                 else {
@@ -396,7 +400,7 @@ static int cell_area_impl(tmat_handle hd, const uint16_t *imgs, int n, int H, in
             }
         }
     }
-    hipFree(din); hipFree(dsm); hipFree(hist); hipFree(kept); hipFree(dpar); hipFree(dthr); hipFree(itab); hipFree(dmaskbuf); hipFree(lohibuf);
+    if (rc) hipStreamSynchronize(s);      // nothing of a failed call stays in flight on the handle's workspaces
     return rc;
 }
 

@@ -174,6 +174,10 @@ struct Ctx {
     bool sep_bf16 = true;                                    // bf16x3 mode also runs the separable layers' pointwise part on the bf16 cores (TMAT_SEP_BF16=0: f32)
     bool stem_fused = true;                                  // the stem recomputed inside block 0's first separable convolution (TMAT_STEM_FUSED=0: stem_kernel writes its tensor)
     bool fused_sep = true;                                   // fused depthwise -> pointwise kernel (sepconv_ws_kernel) where the level allows (TMAT_FUSED_SEP=0: separate kernels)
+    // call-scoped device workspaces of the side tools (cell area), kept between calls: with the reference's default batch of 4 images a
+    // hipMalloc / hipFree pair per buffer and call costs more than the batch's kernels.  Slot = a fixed id per buffer (ws_get below).
+    void *tool_ws[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t tool_ws_bytes[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     // profiling of the dominant kernel family
     bool prof_on = false;
     std::vector<ProfEv> ev_open;
@@ -210,6 +214,17 @@ inline double numpy_pairwise_sum(const double *a, long n)
     long n2 = n / 2;
     n2 -= n2 % 8;
     return numpy_pairwise_sum(a, n2) + numpy_pairwise_sum(a + n2, n - n2);
+}
+
+// device workspace `slot` of the handle with room for `bytes` (grown by reallocation: the caller's stream must not have work in flight on
+// the old buffer -- every user synchronises before it returns); nullptr + set_error on failure
+inline void *ws_get(Ctx *c, int slot, size_t bytes)
+{
+    if (c->tool_ws_bytes[slot] >= bytes && c->tool_ws[slot]) return c->tool_ws[slot];
+    if (c->tool_ws[slot]) { hipFree(c->tool_ws[slot]); c->tool_ws[slot] = nullptr; c->tool_ws_bytes[slot] = 0; }
+    if (!hip_ok(hipMalloc(&c->tool_ws[slot], bytes ? bytes : 16), "hipMalloc(tool workspace)")) { c->tool_ws[slot] = nullptr; return nullptr; }
+    c->tool_ws_bytes[slot] = bytes ? bytes : 16;
+    return c->tool_ws[slot];
 }
 
 // handles made by tmat_create_plain carry no model
