@@ -313,12 +313,13 @@ int tmat_inv_depth_predict(tmat_handle hd, const int *model_ids, int n_models, c
     // cv2.resize(img, img_hw, cv2.INTER_LANCZOS4) (data_prep.py:36): the third positional parameter is `dst`: bilinear
     int rc = TMAT_OK;
     const int nb = std::min(Z, CH);
-    if (!hip_ok(hipMalloc((void **)&din, (size_t)Z * H * W * 2), "hipMalloc") || !hip_ok(hipMalloc((void **)&dsm, (size_t)Z * npx * 2), "hipMalloc") ||
-        !hip_ok(hipMalloc((void **)&itab, (size_t)size * 2 * 4 * 4), "hipMalloc") ||
-        !hip_ok(hipMalloc((void **)&mnmx, (size_t)Z * 2 * 4), "hipMalloc") || !hip_ok(hipMalloc((void **)&dx, (size_t)Z * npx * 3 * 4), "hipMalloc") ||
-        !hip_ok(hipMalloc((void **)&dp, (size_t)Z * n_models * 4), "hipMalloc")) rc = TMAT_E_HIP;
-    for (int i = 0; i < 4 && !rc; i++) if (!hip_ok(hipMalloc((void **)&bufs[i], (size_t)nb * (size / 2) * (size / 2) * 64 * 4), "hipMalloc")) rc = TMAT_E_HIP;
-    if (!rc && !hip_ok(hipMalloc((void **)&col, (size_t)nb * (size / 2) * (size / 2) * STEM_K * 4), "hipMalloc")) rc = TMAT_E_HIP;
+    // workspaces live on the handle between calls (tmat_ctx.h:ws_get): slots 12..22 of this tool
+    din = (uint16_t *)ws_get(c, 12, (size_t)Z * H * W * 2); dsm = (uint16_t *)ws_get(c, 13, (size_t)Z * npx * 2);
+    itab = (int *)ws_get(c, 14, (size_t)size * 2 * 4 * 4); mnmx = (int *)ws_get(c, 15, (size_t)Z * 2 * 4);
+    dx = (float *)ws_get(c, 16, (size_t)Z * npx * 3 * 4); dp = (float *)ws_get(c, 17, (size_t)Z * n_models * 4);
+    for (int i = 0; i < 4; i++) bufs[i] = (float *)ws_get(c, 18 + i, (size_t)nb * (size / 2) * (size / 2) * 64 * 4);
+    col = (float *)ws_get(c, 22, (size_t)nb * (size / 2) * (size / 2) * STEM_K * 4);
+    if (!din || !dsm || !itab || !mnmx || !dx || !dp || !bufs[0] || !bufs[1] || !bufs[2] || !bufs[3] || !col) rc = TMAT_E_HIP;
     if (!rc) {
         // cv::resize takes INTER_AREA's integer mean for an exact halving on both axes (a 512 x 512 slice at the configured 256 x 256);
         // 8-bit sources (tmat_set_input_depth(h, 8)) take its fixed-point bilinear arithmetic
@@ -341,8 +342,7 @@ int tmat_inv_depth_predict(tmat_handle hd, const int *model_ids, int n_models, c
             if (!rc) for (int z = 0; z < Z; z++) for (int mi = 0; mi < n_models; mi++) probs[(size_t)z * n_models + mi] = ph[(size_t)mi * Z + z];     // (Z, n_models)
         }
     }
-    hipFree(din); hipFree(dsm); hipFree(itab); hipFree(mnmx); hipFree(dx); hipFree(dp); hipFree(col);
-    for (float *b : bufs) hipFree(b);
+    if (rc) hipStreamSynchronize(s);      // nothing of a failed call stays in flight on the handle's workspaces
     return rc;
 }
 

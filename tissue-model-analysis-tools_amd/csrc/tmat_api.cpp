@@ -809,7 +809,7 @@ int tmat_debug_poison(tmat_handle h, int byte_pattern)
     if (c->patch_in2) all.push_back({c->patch_in2, pio, false});
     if (c->patch_out) all.push_back({c->patch_out, pio, false});
     if (c->scratch) all.push_back({c->scratch, c->scratch_bytes, false});
-    for (int i = 0; i < 12; i++) if (c->tool_ws[i]) all.push_back({c->tool_ws[i], c->tool_ws_bytes[i], false});
+    for (int i = 0; i < Ctx::N_TOOL_WS; i++) if (c->tool_ws[i]) all.push_back({c->tool_ws[i], c->tool_ws_bytes[i], false});
     all.insert(all.end(), c->pass.ws.begin(), c->pass.ws.end());
     for (const WsEnt &e : all) {
         if (e.host) memset(e.p, byte_pattern, e.bytes);

@@ -174,10 +174,11 @@ struct Ctx {
     bool sep_bf16 = true;                                    // bf16x3 mode also runs the separable layers' pointwise part on the bf16 cores (TMAT_SEP_BF16=0: f32)
     bool stem_fused = true;                                  // the stem recomputed inside block 0's first separable convolution (TMAT_STEM_FUSED=0: stem_kernel writes its tensor)
     bool fused_sep = true;                                   // fused depthwise -> pointwise kernel (sepconv_ws_kernel) where the level allows (TMAT_FUSED_SEP=0: separate kernels)
-    // call-scoped device workspaces of the side tools (cell area), kept between calls: with the reference's default batch of 4 images a
+    // call-scoped device workspaces of the side tools (cell area, invasion depth), kept between calls: with the reference's default batch of 4 images a
     // hipMalloc / hipFree pair per buffer and call costs more than the batch's kernels.  Slot = a fixed id per buffer (ws_get below).
-    void *tool_ws[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t tool_ws_bytes[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static constexpr int N_TOOL_WS = 24;                     // 0-8 cell area, 12-22 invasion depth
+    void *tool_ws[N_TOOL_WS] = {};
+    size_t tool_ws_bytes[N_TOOL_WS] = {};
     // profiling of the dominant kernel family
     bool prof_on = false;
     std::vector<ProfEv> ev_open;
