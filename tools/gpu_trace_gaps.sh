@@ -4,5 +4,5 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/gap_trace
 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/gap_trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-alt --no-cpu-baseline > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
-python3 tools/dev/trace_gaps.py $(find gpurun_out/gap_trace -name "*kernel_trace.csv" | head -1)
+T=$(find gpurun_out/gap_trace -name "*kernel_trace.csv" | head -1); python3 tools/dev/trace_gaps.py $T; python3 tools/dev/trace_overlap.py $T
 rm -rf gpurun_out/gap_trace
