@@ -313,6 +313,9 @@ int tmat_resize_aa_u16(tmat_handle h, const uint16_t *imgs, int n, int H, int W,
  * threshold foreground mean + sd_coef * foreground sd), compute_area_prop (:164-178).
  * area: n fractions of pixels kept.  thresholded (nullable): (n, out_h, out_w) u8, 255 where kept (:87).
  * params (nullable): n x 9 doubles [threshold, weight0, weight1, mean0, mean1, var0, var1, EM iterations, converged].
+ * The call's device workspaces (sized by the largest batch seen) stay on the handle until tmat_destroy: the reference's
+ * default batch is 4 images, for which a hipMalloc / hipFree pair per buffer and call cost more than the kernels.
+ * tmat_inv_depth_predict keeps its workspaces the same way.
  */
 int tmat_cell_area_batch(tmat_handle h, const uint16_t *imgs, int n, int H, int W, int out_h, int out_w, double sd_coef,
                          double *area, uint8_t *thresholded, double *params);
