@@ -353,6 +353,11 @@ int tmat_resnet_predict(tmat_handle h, int model_id, const float *x, int n, int 
  * x_out (nullable): the prepared input (Z, size, size, 3) f32. */
 int tmat_inv_depth_predict(tmat_handle h, const int *model_ids, int n_models, const uint16_t *stack, int Z, int H, int W,
                            int size, float *probs, float *x_out);
+/* The same for n_stacks Z stacks of one (H, W) in ONE call (compute_inv_depth.py:123-166 loops over the stacks; every step is per
+ * slice, so stacks ride together through the classifiers): stacks[k] (Zs[k], H, W) u16 host -- uploaded back to back, no
+ * concatenation on the host --, probs (sum of Zs, n_models) in stack order. */
+int tmat_inv_depth_predict_multi(tmat_handle h, const int *model_ids, int n_models, const uint16_t *const *stacks, const int *Zs,
+                                 int n_stacks, int H, int W, int size, float *probs);
 
 /* device memory helpers so a ctypes host can stage inputs in HBM without torch */
 int tmat_dev_alloc(tmat_handle h, size_t bytes, void **dev_ptr);

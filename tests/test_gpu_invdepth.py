@@ -82,6 +82,30 @@ def test_eight_bit_stacks_take_cv2s_fixed_point_bilinear(plain):
     assert (x != x16).any()
 
 
+def test_stacks_ride_together_without_changing_a_slice(plain):
+    """predict_stacks: stacks of one shape and dtype go through the classifiers in one call (tmat_inv_depth_predict_multi: uploaded back
+    to back, no concatenation on the host), stacks of another shape or dtype start a new call; every slice's probabilities equal what
+    predict_stack gives for its stack alone, bit for bit"""
+    from tmat_amd import inv_depth, synth
+    ens = inv_depth.InvDepthEnsemble(plain, [inv_depth.synth_resnet_weights(s, "conv2_block1_out") for s in (0, 1)])
+    a = synth.synth_stack(1, 3, 300, 360, n_vessels=8)
+    b = synth.synth_stack(2, 2, 300, 360, n_vessels=8)
+    c = synth.synth_stack(3, 2, 280, 300, n_vessels=8)
+    d = (synth.synth_stack(4, 2, 280, 300, n_vessels=8) >> 8).astype(np.uint8)
+    stacks = [a, b, a[:1], c, d, d]
+    got = ens.predict_stacks(stacks)
+    assert len(got) == len(stacks)
+    for s, g in zip(stacks, got):
+        ref = ens.predict_stack(s)
+        assert g.shape == ref.shape == (len(s), 2) and np.array_equal(g.view(np.uint32), ref.view(np.uint32))
+    # a group limited by max_slices splits where the next stack would not fit
+    got2 = ens.predict_stacks(stacks, max_slices=4)
+    for g, g2 in zip(got, got2):
+        assert np.array_equal(g.view(np.uint32), g2.view(np.uint32))
+    with pytest.raises(ValueError):
+        ens.predict_stacks([np.zeros((2, 8, 8), np.float32)])
+
+
 def test_bad_weights_and_arguments(plain):
     from tmat_amd import _lib, inv_depth
     w = inv_depth.synth_resnet_weights(0, "conv2_block1_out")

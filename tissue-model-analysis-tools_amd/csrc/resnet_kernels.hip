@@ -297,10 +297,13 @@ int tmat_resnet_predict(tmat_handle hd, int model_id, const float *x, int n, int
     return rc;
 }
 
-int tmat_inv_depth_predict(tmat_handle hd, const int *model_ids, int n_models, const uint16_t *stack, int Z, int H, int W, int size, float *probs, float *x_out)
+}  // extern "C"
+
+// stacks[k] (Zs[k], H, W) u16 host, k < n_stacks: uploaded back to back (Z = their sum) -- every step of the tool is per slice
+static int inv_depth_impl(tmat_handle hd, const int *model_ids, int n_models, const uint16_t *const *stacks, const int *Zs, int n_stacks, int Z, int H, int W,
+                          int size, float *probs, float *x_out)
 {
     Ctx *c = (Ctx *)hd;
-    if (!c || !model_ids || !stack || !probs || n_models < 1 || Z < 0 || H < 1 || W < 1 || size < 32 || size % 32) { set_error("tmat_inv_depth_predict: bad argument"); return TMAT_E_ARG; }
     for (int i = 0; i < n_models; i++) if (model_ids[i] < 0 || model_ids[i] >= (int)c->resnets.size()) { set_error("tmat_inv_depth_predict: unknown model id"); return TMAT_E_ARG; }
     if (Z == 0) return TMAT_OK;
     TMAT_HIP(hipSetDevice(c->device));
@@ -323,8 +326,15 @@ int tmat_inv_depth_predict(tmat_handle hd, const int *model_ids, int n_models, c
     if (!rc) {
         // cv::resize takes INTER_AREA's integer mean for an exact halving on both axes (a 512 x 512 slice at the configured 256 x 256);
         // 8-bit sources (tmat_set_input_depth(h, 8)) take its fixed-point bilinear arithmetic
-        bool ok = hipMemcpyAsync(din, stack, (size_t)Z * H * W * 2, hipMemcpyHostToDevice, s) == hipSuccess &&
-                  launch_resize_linear_dev(din, Z, H, W, size, size, c->input_sat == 255.f, itab, dsm, s) == 0;
+        bool ok = true;
+        {
+            size_t z0 = 0;
+            for (int k = 0; k < n_stacks && ok; k++) {
+                ok = hipMemcpyAsync(din + z0 * H * W, stacks[k], (size_t)Zs[k] * H * W * 2, hipMemcpyHostToDevice, s) == hipSuccess;
+                z0 += (size_t)Zs[k];
+            }
+        }
+        ok = ok && launch_resize_linear_dev(din, Z, H, W, size, size, c->input_sat == 255.f, itab, dsm, s) == 0;
         if (!ok) { set_error("tmat_inv_depth_predict: upload failed"); rc = TMAT_E_HIP; }
         else {
             const int blocks = (int)((npx + 255) / 256);
@@ -344,6 +354,31 @@ int tmat_inv_depth_predict(tmat_handle hd, const int *model_ids, int n_models, c
     }
     if (rc) hipStreamSynchronize(s);      // nothing of a failed call stays in flight on the handle's workspaces
     return rc;
+}
+
+extern "C" {
+
+int tmat_inv_depth_predict(tmat_handle hd, const int *model_ids, int n_models, const uint16_t *stack, int Z, int H, int W, int size, float *probs, float *x_out)
+{
+    Ctx *c = (Ctx *)hd;
+    if (!c || !model_ids || !stack || !probs || n_models < 1 || Z < 0 || H < 1 || W < 1 || size < 32 || size % 32) { set_error("tmat_inv_depth_predict: bad argument"); return TMAT_E_ARG; }
+    return inv_depth_impl(hd, model_ids, n_models, &stack, &Z, 1, Z, H, W, size, probs, x_out);
+}
+
+int tmat_inv_depth_predict_multi(tmat_handle hd, const int *model_ids, int n_models, const uint16_t *const *stacks, const int *Zs, int n_stacks, int H, int W,
+                                 int size, float *probs)
+{
+    Ctx *c = (Ctx *)hd;
+    if (!c || !model_ids || !stacks || !Zs || !probs || n_models < 1 || n_stacks < 0 || H < 1 || W < 1 || size < 32 || size % 32) {
+        set_error("tmat_inv_depth_predict_multi: bad argument"); return TMAT_E_ARG;
+    }
+    long long Z = 0;
+    for (int k = 0; k < n_stacks; k++) {
+        if (Zs[k] < 0 || (Zs[k] > 0 && !stacks[k])) { set_error("tmat_inv_depth_predict_multi: bad stack"); return TMAT_E_ARG; }
+        Z += Zs[k];
+    }
+    if (Z > 0x7fffffffLL / ((long long)size * size)) { set_error("tmat_inv_depth_predict_multi: too many slices"); return TMAT_E_ARG; }
+    return inv_depth_impl(hd, model_ids, n_models, stacks, Zs, n_stacks, (int)Z, H, W, size, probs, nullptr);
 }
 
 }  // extern "C"

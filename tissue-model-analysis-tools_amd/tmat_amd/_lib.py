@@ -81,6 +81,7 @@ def lib():
     L.tmat_resnet_load.argtypes = [vp, vp, sz, C.POINTER(i)]
     L.tmat_resnet_predict.argtypes = [vp, i, vp, i, i, vp]
     L.tmat_inv_depth_predict.argtypes = [vp, vp, i, vp, i, i, i, i, vp, vp]
+    L.tmat_inv_depth_predict_multi.argtypes = [vp, vp, i, vp, vp, i, i, i, i, vp]
     L.tmat_prof_enable.argtypes = [vp, i]
     L.tmat_debug_poison.argtypes = [vp, i]
     L.tmat_set_precision.argtypes = [vp, i]
@@ -108,7 +109,7 @@ EXPORTS = [
     "tmat_host_permutation", "tmat_host_postprocess",
     "tmat_set_gaussian_table", "tmat_host_gaussian_kernel1d", "tmat_gaussian_f32", "tmat_sato_batch", "tmat_stack_prepare", "tmat_vessel_field",
     "tmat_analyze_stack", "tmat_field_stats", "tmat_field_stats_pruned", "tmat_resize_aa_u16", "tmat_cell_area_batch", "tmat_cell_area_masked", "tmat_resize_linear_u16",
-    "tmat_resnet_load", "tmat_resnet_predict", "tmat_inv_depth_predict",
+    "tmat_resnet_load", "tmat_resnet_predict", "tmat_inv_depth_predict", "tmat_inv_depth_predict_multi",
 ]
 
 

@@ -137,12 +137,26 @@ class InvDepthEnsemble:
         i = 0
         while i < len(stacks):
             a0 = np.asarray(stacks[i])
+            if a0.ndim != 3 or a0.dtype not in (np.uint8, np.uint16):
+                raise ValueError("predict_stacks: expected (Z, H, W) uint8 or uint16 stacks")
             j, nsl = i + 1, a0.shape[0]
             while j < len(stacks) and np.asarray(stacks[j]).shape[1:] == a0.shape[1:] and np.asarray(stacks[j]).dtype == a0.dtype \
                     and nsl + np.asarray(stacks[j]).shape[0] <= max_slices:
                 nsl += np.asarray(stacks[j]).shape[0]
                 j += 1
-            probs = self.predict_stack(np.concatenate([np.asarray(s) for s in stacks[i:j]]) if j > i + 1 else a0)
+            if j > i + 1:
+                # one call, no concatenation on the host: the library uploads the stacks back to back (tmat_inv_depth_predict_multi)
+                from .preprocessing import _source_depth
+                group = [np.ascontiguousarray(np.asarray(s), np.uint16) for s in stacks[i:j]]
+                ptrs = (C.c_void_p * len(group))(*[g.ctypes.data for g in group])
+                zs = np.ascontiguousarray([g.shape[0] for g in group], np.int32)
+                ids = np.ascontiguousarray(self.ids, np.int32)
+                probs = np.empty((nsl, len(ids)), np.float32)
+                with _source_depth(self.handle, a0.dtype):
+                    check(lib().tmat_inv_depth_predict_multi(self.handle.raw, ptr(ids), len(ids), C.cast(ptrs, C.c_void_p), ptr(zs), len(group),
+                                                             a0.shape[1], a0.shape[2], self.size, ptr(probs)), "tmat_inv_depth_predict_multi")
+            else:
+                probs = self.predict_stack(a0)
             z0 = 0
             for k in range(i, j):
                 zk = np.asarray(stacks[k]).shape[0]
