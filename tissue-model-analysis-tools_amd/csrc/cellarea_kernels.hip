@@ -176,7 +176,11 @@ __global__ __launch_bounds__(1024) void gmm_hist_kernel(const unsigned *__restri
     auto xval = [&](int level) -> double { return lo != hi ? (double)(float)(((double)level - dlo) / drange) : fmin(fmax((double)level, 0.0), 1.0); };
     const double n_tot = (double)N, eps10 = 10.0 * 2.220446049250313e-16;
     double w[2], mu[2], var[2];
-    // M step from the one-hot responsibilities of the 2-means partition
+    // M step from responsibilities resp(i, x, r0, r1) -> the level's log-likelihood term (0 for the one-hot start).  The E step's lower bound
+    // is accumulated in the M step's first sweep (round 4: it needs the same log-sum-exp the responsibilities come from -- a sweep of its own
+    // cost 2 exp + 1 log per level and iteration out of 13; the sums are separate accumulators with their own reductions, so nothing changes
+    // in any of them)
+    double ll_sum = 0.0;
     auto m_step = [&](auto resp) {
         double a[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -184,10 +188,12 @@ __global__ __launch_bounds__(1024) void gmm_hist_kernel(const unsigned *__restri
             if (!cnt[i]) continue;
             const double c = (double)cnt[i], x = xval(b0 + i);
             double r0, r1;
-            resp(i, x, r0, r1);
+            const double lse = resp(i, x, r0, r1);
             a[0] += r0 * c; a[1] += r1 * c; a[2] += r0 * (c * x); a[3] += r1 * (c * x);
+            a[4] += c * lse;
         }
         block_sum<6>(a, scratch);
+        ll_sum = a[4];
         const double nk0 = a[0] + eps10, nk1 = a[1] + eps10;
         mu[0] = a[2] / nk0; mu[1] = a[3] / nk1;
         double v[6] = {0, 0, 0, 0, 0, 0};
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(1024) void gmm_hist_kernel(const unsigned *__restri
         var[0] = v[0] / nk0 + GMM_REG_COVAR; var[1] = v[1] / nk1 + GMM_REG_COVAR;
         w[0] = nk0 / n_tot; w[1] = nk1 / n_tot;
     };
-    m_step([&](int i, double, double &r0, double &r1) { r0 = b0 + i <= bestk ? 1.0 : 0.0; r1 = 1.0 - r0; });
+    m_step([&](int i, double, double &r0, double &r1) { r0 = b0 + i <= bestk ? 1.0 : 0.0; r1 = 1.0 - r0; return 0.0; });
     double lower = -INFINITY;
     int iters = 0, converged = 0;
     const double log2pi = 1.8378770664093453;
@@ -213,27 +219,18 @@ __global__ __launch_bounds__(1024) void gmm_hist_kernel(const unsigned *__restri
         const double pc0 = 1.0 / sqrt(var[0]), pc1 = 1.0 / sqrt(var[1]);
         const double lw0 = log(w[0]), lw1 = log(w[1]), lp0 = log(pc0), lp1 = log(pc1);
         const double m0 = mu[0], m1 = mu[1];
-        // E step: log responsibilities per level (kept as a closure: recomputed in the M step instead of stored)
+        // E step: log responsibilities per level (kept as a closure: recomputed in the M step instead of stored); returns the level's
+        // log-sum-exp, whose count-weighted mean is the lower bound
         auto e_resp = [&](int, double x, double &r0, double &r1) {
             const double y0 = (x - m0) * pc0, y1 = (x - m1) * pc1;
             const double a0 = -0.5 * (log2pi + y0 * y0) + lp0 + lw0, a1 = -0.5 * (log2pi + y1 * y1) + lp1 + lw1;
             const double mx = fmax(a0, a1);
             const double lse = mx + log(exp(a0 - mx) + exp(a1 - mx));
             r0 = exp(a0 - lse); r1 = exp(a1 - lse);
+            return lse;
         };
-        double ll[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < GMM_BINS_PER_THREAD; i++) {
-            if (!cnt[i]) continue;
-            const double x = xval(b0 + i);
-            const double y0 = (x - m0) * pc0, y1 = (x - m1) * pc1;
-            const double a0 = -0.5 * (log2pi + y0 * y0) + lp0 + lw0, a1 = -0.5 * (log2pi + y1 * y1) + lp1 + lw1;
-            const double mx = fmax(a0, a1);
-            ll[0] += (double)cnt[i] * (mx + log(exp(a0 - mx) + exp(a1 - mx)));
-        }
-        block_sum<6>(ll, scratch);
-        lower = ll[0] / n_tot;
         m_step(e_resp);
+        lower = ll_sum / n_tot;
         if (fabs(lower - prev) < GMM_TOL) { converged = 1; break; }
     }
     if (t == 0) {
