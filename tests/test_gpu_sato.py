@@ -176,6 +176,26 @@ def test_stack_detect_well_prunes_the_graph_like_the_oracle(plain):
     assert plain_row != row, "the pruning mask should remove something in this case"
 
 
+def test_pooled_workspaces_hold_nothing_a_call_reads_before_writing(plain):
+    """the Z-stack calls take their device blocks from a pool on the handle (blocks of earlier calls, stale contents): with every pooled
+    block filled with 0xFF (NaN / -1) or 0x7F between calls, the same stack and a stack of another geometry give the rows of a fresh
+    handle -- no call reads a location of a recycled block that it has not written"""
+    from tmat_amd import _lib, branches, sato, synth
+    cfg = {"graph_thresh_1": 5, "graph_thresh_2": 10, "graph_smoothing_window": 12, "min_branch_length": 12}
+    sw, mn, mx = branches.graph_px_params(cfg, 384, 1000.0)
+    a = synth.synth_stack(11, 5, 300, 300, n_vessels=12)
+    b = synth.synth_stack(12, 3, 256, 320, n_vessels=10)
+    fresh = _lib.Handle(None, 0)
+    try:
+        want = [sato.analyze_stack(fresh, s, 5, 10, sw, mn, mx, False) for s in (a, b)]
+    finally:
+        fresh.close()
+    for pattern in (0xFF, 0x7F):
+        for s, w in ((a, want[0]), (b, want[1]), (a, want[0])):
+            plain.debug_poison(pattern)
+            assert sato.analyze_stack(plain, s, 5, 10, sw, mn, mx, False) == w
+
+
 def test_bad_arguments(plain):
     from tmat_amd import _lib, sato
     with pytest.raises(ValueError):

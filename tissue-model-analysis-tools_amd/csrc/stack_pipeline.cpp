@@ -21,22 +21,41 @@ void zoom_axis_table(int n_in, int n_out, std::vector<int> &i0, std::vector<int>
 
 namespace {
 
-// device allocations of one call, released together
+// device allocations of one call, released together -- back into the handle's pool (Ctx::ws_pool: blocks by size), from which the next call
+// takes them again: a Z-stack call makes some thirty allocations of a dozen sizes, and a hipMalloc / hipFree pair per block was a tenth of
+// its time.  The pool only ever holds what one call of each geometry needs; tmat_destroy frees it.
 struct Arena {
-    std::vector<void *> ptrs;
+    Ctx *c;
+    std::vector<std::pair<void *, size_t>> blocks;
+    std::vector<void *> ptrs;               // blocks that are not the pool's (morph / DMT workspaces allocated by the caller): freed
     bool ok = true;
+    explicit Arena(Ctx *ctx) : c(ctx) {}
     template <typename T> T *get(size_t count)
     {
-        void *p = nullptr;
         if (!ok) return nullptr;
-        if (!hip_ok(hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)), "hipMalloc")) { ok = false; return nullptr; }
-        ptrs.push_back(p);
-        return (T *)p;
+        const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+        return (T *)get_bytes(bytes);
     }
-    hipStream_t drain = nullptr;            // synchronised before anything is freed: an early error return must not leave async work behind
+    void *get_bytes(size_t bytes)
+    {
+        if (!ok) return nullptr;
+        auto it = c->ws_pool.lower_bound(bytes);
+        if (it != c->ws_pool.end() && it->first <= bytes + bytes / 4 + 4096) {          // close enough in size: reuse
+            void *p = it->second;
+            blocks.push_back({p, it->first});
+            c->ws_pool.erase(it);
+            return p;
+        }
+        void *p = nullptr;
+        if (!hip_ok(hipMalloc(&p, bytes), "hipMalloc")) { ok = false; return nullptr; }
+        blocks.push_back({p, bytes});
+        return p;
+    }
+    hipStream_t drain = nullptr;            // synchronised before anything is released: an early error return must not leave async work behind
     ~Arena()
     {
         if (drain) hipStreamSynchronize(drain);
+        for (auto &b : blocks) c->ws_pool.insert({b.second, b.first});
         for (void *p : ptrs) hipFree(p);
     }
 };
@@ -118,7 +137,7 @@ int vessel_field_dev(Ctx *c, const float *vol, int Z, int h, int w, int form, fl
     if (!thin_dev_supported(h, w)) { set_error("vessel field: image too large for the device thinning kernel"); return TMAT_E_ARG; }
     const int D = Z - 1;
     const size_t npx = (size_t)h * w, nv = (size_t)D * npx;
-    Arena A;
+    Arena A(c);
     A.drain = s;
     float *x = A.get<float>(nv), *vess = A.get<float>(nv), *bufs[7];
     for (float *&b : bufs) b = A.get<float>(nv);
@@ -133,7 +152,7 @@ int vessel_field_dev(Ctx *c, const float *vol, int Z, int h, int w, int form, fl
     unsigned long long *mom = A.get<unsigned long long>(npx * 6);
     int *offs = A.get<int>(2 * (13 + 9));
     void *mws = nullptr;
-    if (A.ok && hip_ok(hipMalloc(&mws, morph_workspace_bytes(1, h, w)), "hipMalloc")) A.ptrs.push_back(mws); else A.ok = false;
+    mws = A.get_bytes(morph_workspace_bytes(1, h, w));
     if (!A.ok) return TMAT_E_HIP;
     {
         const double t[6] = {-1.0, 0.0, 1.0, 1.0, 2.0, 1.0};
@@ -204,7 +223,7 @@ int vessel_field_dev(Ctx *c, const float *vol, int Z, int h, int w, int form, fl
 int stack_resize_aa_dev(Ctx *c, const uint16_t *stack, int Z, int H, int W, int oh, int ow, double *zoomed, float *vol, hipStream_t s)
 {
     const size_t nin = (size_t)Z * H * W;
-    Arena A;
+    Arena A(c);
     A.drain = s;
     double *fa = A.get<double>(nin), *fb = A.get<double>(nin), *lohi = A.get<double>(4);
     unsigned long long *mm = A.get<unsigned long long>(2);
@@ -257,7 +276,7 @@ int stack_resize_aa_dev(Ctx *c, const uint16_t *stack, int Z, int H, int W, int 
 int stack_prepare_dev(Ctx *c, uint16_t *stack, int Z, int H, int W, int oh, int ow, float *vol, hipStream_t s)
 {
     const size_t nin = (size_t)Z * H * W, nout = (size_t)Z * oh * ow;
-    Arena A;
+    Arena A(c);
     A.drain = s;
     double *fa = A.get<double>(nin), *zoomed = A.get<double>(nout);
     if (!A.ok) return TMAT_E_HIP;
@@ -284,7 +303,7 @@ int tmat_gaussian_f32(tmat_handle hd, const float *x, int d0, int d1, int d2, do
     TMAT_HIP(hipSetDevice(c->device));
     const size_t n = (size_t)d0 * d1 * d2;
     hipStream_t s = c->stream;
-    Arena A;
+    Arena A(c);
     A.drain = s;
     float *a = A.get<float>(n), *b = A.get<float>(n);
     if (!A.ok) return TMAT_E_HIP;
@@ -309,7 +328,7 @@ static int well_threshold(tmat_handle hd, const void *img, int is_f64, int H, in
     TMAT_HIP(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const size_t n = (size_t)H * W;
-    Arena A;
+    Arena A(c);
     A.drain = s;
     float *a = A.get<float>(is_f64 ? 1 : n), *b = A.get<float>(is_f64 ? 1 : n), *mm = A.get<float>(2);
     double *da = A.get<double>(is_f64 ? n : 1), *db = A.get<double>(is_f64 ? n : 1), *dmm = A.get<double>(2);
@@ -360,7 +379,7 @@ int tmat_canny_mask(tmat_handle hd, const uint8_t *mask, int H, int W, double si
     const int r = gauss_radius(sigma, 4.0);
     const int Hp = H + 2 * r, Wp = W + 2 * r;
     const size_t npx = (size_t)H * W, npad = (size_t)Hp * Wp;
-    Arena A;
+    Arena A(c);
     A.drain = s;
     uint8_t *m = A.get<uint8_t>(npx), *e = A.get<uint8_t>(npx);
     double *pa = A.get<double>(npad), *pb = A.get<double>(npad), *pt = A.get<double>(npad);
@@ -400,7 +419,7 @@ int tmat_sato_batch(tmat_handle hd, const float *imgs, int n, int hh, int ww, co
     TMAT_HIP(hipSetDevice(c->device));
     const size_t total = (size_t)n * hh * ww;
     hipStream_t s = c->stream;
-    Arena A;
+    Arena A(c);
     A.drain = s;
     float *raw = A.get<float>(total), *x = A.get<float>(total), *best = A.get<float>(total), *bufs[7];
     for (float *&b : bufs) b = A.get<float>(total);
@@ -419,7 +438,7 @@ int tmat_stack_prepare(tmat_handle hd, const uint16_t *stack, int Z, int H, int 
     if (!c || !stack || !vol || Z < 1 || H < 1 || W < 1 || out_h < 1 || out_w < 1) { set_error("tmat_stack_prepare: bad argument"); return TMAT_E_ARG; }
     TMAT_HIP(hipSetDevice(c->device));
     const size_t nin = (size_t)Z * H * W, nout = (size_t)Z * out_h * out_w;
-    Arena A;
+    Arena A(c);
     A.drain = c->stream;
     uint16_t *ds = A.get<uint16_t>(nin);
     float *dv = A.get<float>(nout);
@@ -441,7 +460,7 @@ int tmat_vessel_field(tmat_handle hd, const float *vol, int Z, int hh, int ww, i
     }
     TMAT_HIP(hipSetDevice(c->device));
     const size_t nvol = (size_t)Z * hh * ww, npx = (size_t)hh * ww;
-    Arena A;
+    Arena A(c);
     A.drain = c->stream;
     float *dv = A.get<float>(nvol), *df = A.get<float>(npx);
     if (!A.ok) return TMAT_E_HIP;
@@ -458,13 +477,13 @@ static int field_stats_dev(Ctx *c, const float *field, int fh, int fw, float t1,
                            const uint8_t *pruning_mask, int64_t index, tmat_row *row, hipStream_t s)
 {
     const size_t npx = (size_t)fh * fw, nE = dmt_edge_count(fh, fw);
-    Arena A;
+    Arena A(c);
     A.drain = s;
     float *f255 = A.get<float>(npx), *mnmx = A.get<float>(2);
     int32_t *ids = A.get<int32_t>(nE);
     int *m = A.get<int>(1);
     void *dws = nullptr;
-    if (A.ok && hip_ok(hipMalloc(&dws, dmt_workspace_bytes(1, fh, fw)), "hipMalloc")) A.ptrs.push_back(dws); else A.ok = false;
+    dws = A.get_bytes(dmt_workspace_bytes(1, fh, fw));
     if (!A.ok) return TMAT_E_HIP;
     launch_rescale255(field, 1, (int)npx, mnmx, mnmx + 1, f255, s);
     std::vector<float> f255_host(npx);
@@ -478,7 +497,7 @@ static int field_stats_dev(Ctx *c, const float *field, int fh, int fw, float t1,
         uint8_t *dkind = A.get<uint8_t>(nE);
         float *dpers = A.get<float>(nE);
         void *sws = nullptr;
-        if (A.ok && hip_ok(hipMalloc(&sws, dmt_sweep_workspace_bytes(1, fh, fw)), "hipMalloc")) A.ptrs.push_back(sws); else A.ok = false;
+        sws = A.get_bytes(dmt_sweep_workspace_bytes(1, fh, fw));
         if (!A.ok) return TMAT_E_HIP;
         if (dmt_sweeps_dev(f255, ids, m, 1, fh, fw, sws, dkind, dpers, s)) { set_error("field stats: device sweeps failed"); return TMAT_E_HIP; }
         kind_host.resize(nE); pers_host.resize(nE);
@@ -508,7 +527,7 @@ int tmat_field_stats_pruned(tmat_handle hd, const float *field, int fh, int fw, 
     Ctx *c = (Ctx *)hd;
     if (!c || !field || !row || fh < 2 || fw < 2) { set_error("tmat_field_stats: bad argument"); return TMAT_E_ARG; }
     TMAT_HIP(hipSetDevice(c->device));
-    Arena A;
+    Arena A(c);
     A.drain = c->stream;
     float *df = A.get<float>((size_t)fh * fw);
     if (!A.ok) return TMAT_E_HIP;
@@ -530,7 +549,7 @@ int tmat_resize_aa_u16(tmat_handle hd, const uint16_t *imgs, int n, int H, int W
     if (!c || !imgs || !out || n < 1 || H < 1 || W < 1 || out_h < 1 || out_w < 1) { set_error("tmat_resize_aa_u16: bad argument"); return TMAT_E_ARG; }
     TMAT_HIP(hipSetDevice(c->device));
     const size_t nin = (size_t)n * H * W, nout = (size_t)n * out_h * out_w;
-    Arena A;
+    Arena A(c);
     A.drain = c->stream;
     uint16_t *ds = A.get<uint16_t>(nin);
     double *dz = A.get<double>(nout);
@@ -558,7 +577,7 @@ int tmat_analyze_stack(tmat_handle hd, const uint16_t *stack, int Z, int H, int 
     if (fh < 2 || fw < 2) { set_error("tmat_analyze_stack: downsampled shape is empty"); return TMAT_E_ARG; }
     const size_t nin = (size_t)Z * H * W, npx = (size_t)fh * fw;
     hipStream_t s = c->stream;
-    Arena A;
+    Arena A(c);
     A.drain = s;
     uint16_t *ds = A.get<uint16_t>(nin);
     float *vol = A.get<float>((size_t)Z * npx), *field = A.get<float>(npx);

@@ -661,6 +661,7 @@ void tmat_destroy(tmat_handle h)
     if (c->win1d) hipFree(c->win1d);
     if (c->ma_table) hipFree(c->ma_table);
     for (void *p : c->tool_ws) if (p) hipFree(p);
+    for (auto &b : c->ws_pool) hipFree(b.second);
     for (auto &g : c->gauss_dev) hipFree(g.second);
     for (auto &m : c->resnets) for (void *p : m.owned) hipFree(p);
     c->free_pass();
@@ -810,6 +811,7 @@ int tmat_debug_poison(tmat_handle h, int byte_pattern)
     if (c->patch_out) all.push_back({c->patch_out, pio, false});
     if (c->scratch) all.push_back({c->scratch, c->scratch_bytes, false});
     for (int i = 0; i < Ctx::N_TOOL_WS; i++) if (c->tool_ws[i]) all.push_back({c->tool_ws[i], c->tool_ws_bytes[i], false});
+    for (auto &b : c->ws_pool) all.push_back({b.second, b.first, false});
     all.insert(all.end(), c->pass.ws.begin(), c->pass.ws.end());
     for (const WsEnt &e : all) {
         if (e.host) memset(e.p, byte_pattern, e.bytes);

@@ -179,6 +179,7 @@ struct Ctx {
     static constexpr int N_TOOL_WS = 24;                     // 0-8 cell area, 12-22 invasion depth
     void *tool_ws[N_TOOL_WS] = {};
     size_t tool_ws_bytes[N_TOOL_WS] = {};
+    std::multimap<size_t, void *> ws_pool;                   // released call-scoped blocks of the Z-stack tool, by size (stack_pipeline.cpp:Arena)
     // profiling of the dominant kernel family
     bool prof_on = false;
     std::vector<ProfEv> ev_open;
