@@ -51,7 +51,7 @@ def main():
     alg_bytes = 1024 * 1024 * 2 + 3 * 512 * 512 * 2 + 512 * 512
     line["roofline"] = {"bound": "hbm", "achieved": alg_bytes * a.images / dt / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": alg_bytes * a.images / dt / 1e9 / 8000.0, "traffic": None,
-                        "note": "whole tool, PCIe inclusive (2 MB/image of H2D at <= 63 GB/s = at most 31 500 images/s); per kernel see profiles/r03_config5_kernel_stats.csv"}
+                        "note": "whole tool, PCIe inclusive (2 MB/image of H2D at <= 63 GB/s = at most 31 500 images/s); per kernel see profiles/r04_config5_kernel_stats.csv"}
     if not a.no_cpu:
         from oracle import cellarea as ca
         c0 = time.perf_counter()
