@@ -274,6 +274,8 @@ int tmat_vessel_field(tmat_handle h, const float *vol, int Z, int hh, int ww, in
  * The whole per-image compute of analyze_img for a Z stack (compute_branches.py:224-306, 391-426, 455-457; no well
  * mask): stack (Z, H, W) u16 host -> one result row.  The field is (round(H ds_width / W), ds_width); the graph
  * parameters are those of tmat_analyze_batch.  field_out (nullable) receives the vesselness image.
+ * The device blocks a Z-stack call allocates (this and the stage-wise entry points above) go back to a pool on the handle
+ * when it returns and are taken from there by the next call; tmat_destroy frees the pool.
  */
 int tmat_analyze_stack(tmat_handle h, const uint16_t *stack, int Z, int H, int W, int ds_width, int hessian,
                        float graph_thresh_1, float graph_thresh_2, int smoothing_window_px, int min_branch_length_px,
