@@ -626,7 +626,9 @@ int tmat_zproj_batch(tmat_handle hd, const uint16_t *stacks, int n, int Z, int H
     const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n, ((size_t)1 << 30) / per_in));   // <= 1 GiB of stacks at a time
     uint16_t *din = nullptr; void *dout = nullptr;
     int rc = TMAT_OK;
-    if (!hip_ok(hipMalloc((void **)&din, (size_t)chunk * per_in), "hipMalloc") || !hip_ok(hipMalloc(&dout, (size_t)chunk * npx * osz), "hipMalloc")) rc = TMAT_E_HIP;
+    // the staging buffers stay on the handle between calls (tmat_ctx.h:ws_get, slots 9 and 10)
+    din = (uint16_t *)ws_get(c, 9, (size_t)chunk * per_in); dout = ws_get(c, 10, (size_t)chunk * npx * osz);
+    if (!din || !dout) rc = TMAT_E_HIP;
     for (int i0 = 0; i0 < n && !rc; i0 += chunk) {
         const int k = std::min(chunk, n - i0);
         if (!hip_ok(hipMemcpyAsync(din, stacks + (size_t)i0 * Z * npx, (size_t)k * per_in, hipMemcpyHostToDevice, c->stream), "H2D")) { rc = TMAT_E_HIP; break; }
@@ -635,7 +637,7 @@ int tmat_zproj_batch(tmat_handle hd, const uint16_t *stacks, int n, int Z, int H
         if (!hip_ok(hipMemcpyAsync((char *)out + (size_t)i0 * npx * osz, dout, (size_t)k * npx * osz, hipMemcpyDeviceToHost, c->stream), "D2H") ||
             !hip_ok(hipStreamSynchronize(c->stream), "sync")) rc = TMAT_E_HIP;
     }
-    hipFree(din); hipFree(dout);
+    if (rc) hipStreamSynchronize(c->stream);
     return rc;
 }
 

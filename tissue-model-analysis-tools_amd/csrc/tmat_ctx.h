@@ -176,7 +176,7 @@ struct Ctx {
     bool fused_sep = true;                                   // fused depthwise -> pointwise kernel (sepconv_ws_kernel) where the level allows (TMAT_FUSED_SEP=0: separate kernels)
     // call-scoped device workspaces of the side tools (cell area, invasion depth), kept between calls: with the reference's default batch of 4 images a
     // hipMalloc / hipFree pair per buffer and call costs more than the batch's kernels.  Slot = a fixed id per buffer (ws_get below).
-    static constexpr int N_TOOL_WS = 24;                     // 0-8 cell area, 12-22 invasion depth
+    static constexpr int N_TOOL_WS = 24;                     // 0-8 cell area, 9-10 Z projection, 12-22 invasion depth
     void *tool_ws[N_TOOL_WS] = {};
     size_t tool_ws_bytes[N_TOOL_WS] = {};
     std::multimap<size_t, void *> ws_pool;                   // released call-scoped blocks of the Z-stack tool, by size (stack_pipeline.cpp:Arena)
